@@ -1,0 +1,58 @@
+// Internal declarations shared by the HIP translation units of libdodt_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/dodt_hip.h"
+
+namespace dodt {
+
+void set_error(const char* fmt, ...);
+
+#define DODT_HIP_CHECK(expr)                                                   \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            dodt::set_error("%s failed: %s (%s:%d)", #expr,                    \
+                            hipGetErrorString(e_), __FILE__, __LINE__);        \
+            return DODT_ERR_HIP;                                               \
+        }                                                                      \
+    } while (0)
+
+#define DODT_REQUIRE(cond, ...)                                                \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            dodt::set_error(__VA_ARGS__);                                      \
+            return DODT_ERR_INVALID;                                           \
+        }                                                                      \
+    } while (0)
+
+#define DODT_LAUNCH_CHECK() DODT_HIP_CHECK(hipGetLastError())
+
+// Scratch buffer that only ever grows; never freed inside a launch function.
+struct Scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);
+    void release();
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace dodt
+
+struct dodt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    dodt::Scratch vox_ws;    // voxeliser: touched list + counters
+    dodt::Scratch anchor_ws; // anchor filter: mask + block counts
+    dodt::Scratch nms_ws;    // NMS: keys, sorted boxes, suppression mask
+    int num_cus = 256;
+};

@@ -1,0 +1,482 @@
+// VGG-pyramid feature extractor for gfx950.
+//
+// Reference topology: avod/core/feature_extractors/bev_vgg_pyramid.py:57-169 and
+// img_vgg_pyramid.py:58-171 (see oracle/extractors.py); 1x1 bottleneck
+// avod/core/models/dt_rpn_model.py:298-322.  Every conv is slim.conv2d /
+// slim.conv2d_transpose with batch-norm (inference form, no gamma, eps 1e-3) and
+// ReLU, no bias.
+//
+// Data layout in HBM: activations NHWC float32, one buffer per pyramid level;
+// the decoder's concat inputs are single buffers (conv_k | upconv_k side by
+// side in the channel dimension) that the two producing kernels write into
+// directly, so no concat copy exists.  Both frames of a pair are one batch.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_kernels.h"
+
+namespace {
+
+using dodt::ConvArgs;
+
+// ---------------------------------------------------------------------------
+// kernel instantiations
+// ---------------------------------------------------------------------------
+struct KernelVariant {
+    int TW, MTB, WM, WN, BN, CK;
+    bool deconv;
+    int TH, lds_bytes;
+    void (*launch)(const ConvArgs&, dim3 grid, hipStream_t s);
+    hipError_t (*prepare)();
+};
+
+template <int TW, int MTB, int WM, int WN, int BN, int CK, bool DECONV>
+struct Inst {
+    using Cfg = dodt::ConvCfg<TW, MTB, WM, WN, BN, CK, DECONV>;
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL((dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, CK, DECONV>), grid,
+                           dim3(256), Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(
+            reinterpret_cast<const void*>(
+                &dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, CK, DECONV>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        return KernelVariant{TW, MTB, WM, WN, BN, CK, DECONV, Cfg::TH, Cfg::kLdsBytes, &launch,
+                             &prepare};
+    }
+};
+
+const std::vector<KernelVariant>& variants() {
+    static const std::vector<KernelVariant> v = {
+        Inst<32, 16, 4, 1, 32, 6, false>::variant(),
+        Inst<32, 16, 4, 1, 32, 16, false>::variant(),
+        Inst<16, 16, 4, 1, 32, 16, false>::variant(),
+        Inst<16, 16, 4, 1, 64, 16, false>::variant(),
+        Inst<16, 12, 4, 1, 32, 4, false>::variant(),
+        Inst<16, 12, 4, 1, 32, 16, false>::variant(),
+        Inst<8, 8, 4, 1, 32, 16, false>::variant(),
+        Inst<8, 8, 4, 1, 64, 16, false>::variant(),
+        Inst<8, 4, 2, 2, 128, 8, false>::variant(),
+        Inst<8, 4, 4, 1, 64, 16, false>::variant(),
+        Inst<4, 4, 2, 2, 128, 8, false>::variant(),
+        Inst<4, 4, 4, 1, 64, 16, false>::variant(),
+        Inst<16, 4, 4, 1, 32, 16, true>::variant(),
+        Inst<8, 4, 4, 1, 32, 16, true>::variant(),
+        Inst<4, 4, 4, 1, 32, 16, true>::variant(),
+    };
+    return v;
+}
+
+// smallest padded pixel count wins; ties go to the larger output tile
+int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
+    const auto& vs = variants();
+    int best = -1;
+    double best_cost = 1e300;
+    for (size_t i = 0; i < vs.size(); ++i) {
+        const KernelVariant& v = vs[i];
+        if (v.deconv != deconv || Cout % v.BN != 0 || Cin % v.CK != 0) continue;
+        const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;
+        // mild preference for more work per staged byte
+        const double cost = padded * (1.0 + 4.0 / (v.MTB * 32.0 / 32.0) / 100.0 + 1.0 / v.BN);
+        if (cost < best_cost) { best_cost = cost; best = (int)i; }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------
+// small HBM-bound helpers
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+maxpool2x2_kernel(const float* __restrict__ in, int H, int W, int C, int in_ld,
+                  long long in_frame_stride, float* __restrict__ out, int frames) {
+    // one lane per (output pixel, 4 channels); VALID 2x2 stride 2
+    const int OH = H / 2, OW = W / 2, G = C / 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)frames * OH * OW * G;
+    if (t >= total) return;
+    const int g = (int)(t % G);
+    long long r = t / G;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int f = (int)(r / OH);
+    const float* p = in + (size_t)f * in_frame_stride + ((size_t)(2 * oy) * W + 2 * ox) * in_ld + g * 4;
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + in_ld);
+    const float4 c = *reinterpret_cast<const float4*>(p + (size_t)W * in_ld);
+    const float4 d = *reinterpret_cast<const float4*>(p + (size_t)W * in_ld + in_ld);
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    reinterpret_cast<float4*>(out)[t] = o;
+}
+
+// 1x1 conv to one channel + batch-norm + ReLU; 8 lanes per pixel, float4 each
+__global__ void __launch_bounds__(256)
+bottleneck32_kernel(const float* __restrict__ in, long long n_pix, const float* __restrict__ w,
+                    float scale, float shift, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pix = t >> 3;
+    const int g = (int)(t & 7);
+    float s = 0.0f;
+    if (pix < n_pix) {
+        const float4 v = reinterpret_cast<const float4*>(in)[pix * 8 + g];
+        const float4 k = reinterpret_cast<const float4*>(w)[g];
+        s = ((v.x * k.x + v.y * k.y) + v.z * k.z) + v.w * k.w;
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (pix < n_pix && g == 0) out[pix] = fmaxf(s * scale + shift, 0.0f);
+}
+
+__global__ void __launch_bounds__(256)
+copy_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4_per_frame,
+                 long long src_frame_stride4, long long dst_frame_stride4, int frames) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4_per_frame * frames) return;
+    const int f = (int)(t / n4_per_frame);
+    const long long i = t - (long long)f * n4_per_frame;
+    dst[f * dst_frame_stride4 + i] = src[f * src_frame_stride4 + i];
+}
+
+// ---------------------------------------------------------------------------
+// extractor object
+// ---------------------------------------------------------------------------
+struct Buffer {
+    int H = 0, W = 0, C = 0;
+    float* ptr = nullptr;
+    size_t frame_floats() const { return (size_t)H * W * C; }
+};
+
+struct Layer {
+    std::string name;
+    bool deconv = false;
+    int H = 0, W = 0;  // GEMM grid (conv: output size; deconv: input size)
+    int Cin = 0, Cout = 0;
+    int src = -1, src_coff = 0;
+    int dst = -1, dst_coff = 0;
+    int variant = -1;
+    float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+    bool loaded = false;
+    int real_cin = 0;  // channels that carry data (conv1_1 of the image net: 3 of 4)
+};
+
+enum Buf { X0, C1A, CAT1, P1, C2A, CAT2, P2, C3A, C3B, CAT3, P3, C4A, C4B, C4C, F3, F2, F1, NBUF };
+
+}  // namespace
+
+struct dodt_extractor {
+    dodt_ctx* ctx = nullptr;
+    int in_h = 0, in_w = 0, in_c = 0, pad_top = 0, batch = 0;
+    int H = 0, W = 0;  // padded input size
+    Buffer buf[NBUF];
+    std::vector<Layer> layers;
+    float* d_bneck_w = nullptr;
+    float bneck_scale = 1.0f, bneck_shift = 0.0f;
+    bool bneck_loaded = false;
+    double flops = 0.0;
+};
+
+namespace {
+
+int find_layer(dodt_extractor* ex, const char* name) {
+    for (size_t i = 0; i < ex->layers.size(); ++i)
+        if (ex->layers[i].name == name) return (int)i;
+    return -1;
+}
+
+int buffer_for_layer_output(const Layer& l) { return l.dst; }
+
+int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h) {
+    const KernelVariant& v = variants()[l.variant];
+    const Buffer& src = ex->buf[l.src];
+    const Buffer& dst = ex->buf[l.dst];
+    ConvArgs a;
+    a.in = src.ptr;
+    a.out = override_out ? override_out : dst.ptr;
+    a.w = l.d_w;
+    a.scale = l.d_scale;
+    a.shift = l.d_shift;
+    a.H = l.H;
+    a.W = l.W;
+    a.Cin = l.Cin;
+    a.Cout = l.Cout;
+    a.in_ld = src.C;
+    a.in_coff = l.src_coff;
+    a.out_ld = dst.C;
+    a.out_coff = l.dst_coff;
+    a.in_frame_stride = (long long)src.frame_floats();
+    a.out_frame_stride = override_out ? (long long)out_h * dst.W * dst.C : (long long)dst.frame_floats();
+    a.tiles_x = dodt::ceil_div(l.W, v.TW);
+    a.tiles_y = dodt::ceil_div(l.H, v.TH);
+    a.relu = 1;
+    a.out_y0 = out_y0;
+    dim3 grid(a.tiles_x * a.tiles_y * ex->batch, l.Cout / v.BN);
+    v.launch(a, grid, ex->ctx->stream);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int run_pool(dodt_extractor* ex, int src, int dst) {
+    const Buffer& s = ex->buf[src];
+    const Buffer& d = ex->buf[dst];
+    const long long total = (long long)ex->batch * d.H * d.W * (d.C / 4);
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       ex->ctx->stream, s.ptr, s.H, s.W, d.C, s.C, (long long)s.frame_floats(),
+                       d.ptr, ex->batch);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c, int pad_top,
+                          int batch, dodt_extractor** out) {
+    DODT_REQUIRE(ctx && out, "dodt_extractor_create: NULL argument");
+    DODT_REQUIRE(kind == DODT_EXTRACTOR_VGG_PYR, "dodt_extractor_create: unknown kind %d", kind);
+    DODT_REQUIRE(in_h > 0 && in_w > 0 && in_c >= 2 && in_c % 2 == 0 && pad_top >= 0 && batch >= 1,
+                 "dodt_extractor_create: bad sizes (in_c must be even)");
+    const int H = in_h + pad_top, W = in_w;
+    DODT_REQUIRE(H % 8 == 0 && W % 8 == 0,
+                 "dodt_extractor_create: padded input %dx%d must be divisible by 8 "
+                 "(three 2x2 pools, three stride-2 upconvs)", H, W);
+    for (const KernelVariant& v : variants()) DODT_HIP_CHECK(v.prepare());
+
+    dodt_extractor* ex = new dodt_extractor();
+    ex->ctx = ctx;
+    ex->in_h = in_h; ex->in_w = in_w; ex->in_c = in_c; ex->pad_top = pad_top; ex->batch = batch;
+    ex->H = H; ex->W = W;
+    auto setb = [&](int id, int h, int w, int c) { ex->buf[id].H = h; ex->buf[id].W = w; ex->buf[id].C = c; };
+    setb(X0, H, W, in_c);
+    setb(C1A, H, W, 32); setb(CAT1, H, W, 64); setb(P1, H / 2, W / 2, 32);
+    setb(C2A, H / 2, W / 2, 64); setb(CAT2, H / 2, W / 2, 128); setb(P2, H / 4, W / 4, 64);
+    setb(C3A, H / 4, W / 4, 128); setb(C3B, H / 4, W / 4, 128); setb(CAT3, H / 4, W / 4, 256);
+    setb(P3, H / 8, W / 8, 128);
+    setb(C4A, H / 8, W / 8, 256); setb(C4B, H / 8, W / 8, 256); setb(C4C, H / 8, W / 8, 256);
+    setb(F3, H / 4, W / 4, 64); setb(F2, H / 2, W / 2, 32); setb(F1, H, W, 32);
+    for (int i = 0; i < NBUF; ++i) {
+        const size_t bytes = ex->buf[i].frame_floats() * batch * sizeof(float);
+        hipError_t e = hipMalloc(&ex->buf[i].ptr, bytes);
+        if (e != hipSuccess) {
+            dodt::set_error("dodt_extractor_create: hipMalloc(%zu) failed: %s", bytes,
+                            hipGetErrorString(e));
+            dodt_extractor_destroy(ex);
+            return DODT_ERR_HIP;
+        }
+    }
+    // the pad rows of X0 stay zero for the life of the extractor
+    DODT_HIP_CHECK(hipMemsetAsync(ex->buf[X0].ptr, 0,
+                                  ex->buf[X0].frame_floats() * batch * sizeof(float), ctx->stream));
+
+    auto add = [&](const char* name, bool deconv, int h, int w, int cin, int cout, int src,
+                   int src_coff, int dst, int dst_coff) {
+        Layer l;
+        l.name = name; l.deconv = deconv; l.H = h; l.W = w; l.Cin = cin; l.Cout = cout;
+        l.src = src; l.src_coff = src_coff; l.dst = dst; l.dst_coff = dst_coff;
+        l.variant = pick_variant(deconv, h, w, cin, cout);
+        l.real_cin = cin;
+        ex->layers.push_back(l);
+    };
+    add("conv1_1", false, H, W, in_c, 32, X0, 0, C1A, 0);
+    add("conv1_2", false, H, W, 32, 32, C1A, 0, CAT1, 0);
+    add("conv2_1", false, H / 2, W / 2, 32, 64, P1, 0, C2A, 0);
+    add("conv2_2", false, H / 2, W / 2, 64, 64, C2A, 0, CAT2, 0);
+    add("conv3_1", false, H / 4, W / 4, 64, 128, P2, 0, C3A, 0);
+    add("conv3_2", false, H / 4, W / 4, 128, 128, C3A, 0, C3B, 0);
+    add("conv3_3", false, H / 4, W / 4, 128, 128, C3B, 0, CAT3, 0);
+    add("conv4_1", false, H / 8, W / 8, 128, 256, P3, 0, C4A, 0);
+    add("conv4_2", false, H / 8, W / 8, 256, 256, C4A, 0, C4B, 0);
+    add("conv4_3", false, H / 8, W / 8, 256, 256, C4B, 0, C4C, 0);
+    add("upconv3", true, H / 8, W / 8, 256, 128, C4C, 0, CAT3, 128);
+    add("pyramid_fusion3", false, H / 4, W / 4, 256, 64, CAT3, 0, F3, 0);
+    add("upconv2", true, H / 4, W / 4, 64, 64, F3, 0, CAT2, 64);
+    add("pyramid_fusion2", false, H / 2, W / 2, 128, 32, CAT2, 0, F2, 0);
+    add("upconv1", true, H / 2, W / 2, 32, 32, F2, 0, CAT1, 32);
+    add("pyramid_fusion1", false, H, W, 64, 32, CAT1, 0, F1, 0);
+    for (const Layer& l : ex->layers) {
+        if (l.variant < 0) {
+            dodt::set_error("dodt_extractor_create: no kernel variant for layer %s (%dx%d %d->%d)",
+                            l.name.c_str(), l.H, l.W, l.Cin, l.Cout);
+            dodt_extractor_destroy(ex);
+            return DODT_ERR_UNSUPPORTED;
+        }
+    }
+    if (getenv("DODT_DEBUG_PLAN")) {
+        for (const Layer& l : ex->layers) {
+            const KernelVariant& v = variants()[l.variant];
+            fprintf(stderr, "[dodt] %-16s %4dx%-4d %3d->%-3d TW%d TH%d BN%d CK%d lds %d grid %dx%d\n",
+                    l.name.c_str(), l.H, l.W, l.Cin, l.Cout, v.TW, v.TH, v.BN, v.CK, v.lds_bytes,
+                    dodt::ceil_div(l.W, v.TW) * dodt::ceil_div(l.H, v.TH) * batch, l.Cout / v.BN);
+        }
+    }
+    *out = ex;
+    return DODT_OK;
+}
+
+int dodt_extractor_destroy(dodt_extractor* ex) {
+    if (!ex) return DODT_OK;
+    if (ex->ctx) (void)hipStreamSynchronize(ex->ctx->stream);
+    for (int i = 0; i < NBUF; ++i)
+        if (ex->buf[i].ptr) (void)hipFree(ex->buf[i].ptr);
+    for (Layer& l : ex->layers) {
+        if (l.d_w) (void)hipFree(l.d_w);
+        if (l.d_scale) (void)hipFree(l.d_scale);
+        if (l.d_shift) (void)hipFree(l.d_shift);
+    }
+    if (ex->d_bneck_w) (void)hipFree(ex->d_bneck_w);
+    delete ex;
+    return DODT_OK;
+}
+
+int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* w, int kh, int kw,
+                             int c_a, int c_b, const float* beta, const float* mean,
+                             const float* var) {
+    DODT_REQUIRE(ex && name && w && beta && mean && var, "dodt_extractor_set_layer: NULL argument");
+    hipStream_t s = ex->ctx->stream;
+    if (std::strcmp(name, "bottleneck") == 0) {
+        DODT_REQUIRE(kh == 1 && kw == 1 && c_a == 32 && c_b == 1,
+                     "bottleneck must be (1,1,32,1), got (%d,%d,%d,%d)", kh, kw, c_a, c_b);
+        if (!ex->d_bneck_w) DODT_HIP_CHECK(hipMalloc(&ex->d_bneck_w, 32 * sizeof(float)));
+        DODT_HIP_CHECK(hipMemcpyAsync(ex->d_bneck_w, w, 32 * sizeof(float), hipMemcpyHostToDevice, s));
+        DODT_HIP_CHECK(hipStreamSynchronize(s));
+        const float inv = 1.0f / std::sqrt(var[0] + 0.001f);
+        ex->bneck_scale = inv;
+        ex->bneck_shift = beta[0] - mean[0] * inv;
+        ex->bneck_loaded = true;
+        return DODT_OK;
+    }
+    const int li = find_layer(ex, name);
+    DODT_REQUIRE(li >= 0, "dodt_extractor_set_layer: unknown layer '%s'", name);
+    Layer& l = ex->layers[li];
+    DODT_REQUIRE(kh == 3 && kw == 3, "layer %s: kernel must be 3x3", name);
+    // TF layouts: conv2d (kh,kw,cin,cout); conv2d_transpose (kh,kw,cout,cin)
+    const int cin = l.deconv ? c_b : c_a, cout = l.deconv ? c_a : c_b;
+    DODT_REQUIRE(cout == l.Cout && cin <= l.Cin && (cin == l.Cin || li == 0),
+                 "layer %s: expected %d->%d channels, got %d->%d", name, l.Cin, l.Cout, cin, cout);
+    const KernelVariant& v = variants()[l.variant];
+    const int nchunks = l.Cin / v.CK, ntiles = l.Cout / v.BN;
+    std::vector<float> blocked((size_t)9 * l.Cin * l.Cout, 0.0f);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) {
+                const float val = l.deconv ? w[((size_t)tap * cout + co) * cin + ci]
+                                           : w[((size_t)tap * cin + ci) * cout + co];
+                const int nt = co / v.BN, n = co % v.BN, ch = ci / v.CK, c = ci % v.CK;
+                blocked[((((size_t)nt * nchunks + ch) * 9 + tap) * v.CK + c) * v.BN + n] = val;
+            }
+    (void)ntiles;
+    std::vector<float> scale(l.Cout), shift(l.Cout);
+    for (int co = 0; co < l.Cout; ++co) {
+        const float inv = 1.0f / std::sqrt(var[co] + 0.001f);
+        scale[co] = inv;
+        shift[co] = beta[co] - mean[co] * inv;
+    }
+    if (!l.d_w) DODT_HIP_CHECK(hipMalloc(&l.d_w, blocked.size() * sizeof(float)));
+    if (!l.d_scale) DODT_HIP_CHECK(hipMalloc(&l.d_scale, l.Cout * sizeof(float)));
+    if (!l.d_shift) DODT_HIP_CHECK(hipMalloc(&l.d_shift, l.Cout * sizeof(float)));
+    DODT_HIP_CHECK(hipMemcpyAsync(l.d_w, blocked.data(), blocked.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, s));
+    DODT_HIP_CHECK(hipMemcpyAsync(l.d_scale, scale.data(), l.Cout * sizeof(float),
+                                  hipMemcpyHostToDevice, s));
+    DODT_HIP_CHECK(hipMemcpyAsync(l.d_shift, shift.data(), l.Cout * sizeof(float),
+                                  hipMemcpyHostToDevice, s));
+    DODT_HIP_CHECK(hipStreamSynchronize(s));
+    l.loaded = true;
+    l.real_cin = cin;
+    return DODT_OK;
+}
+
+int dodt_extractor_input(dodt_extractor* ex, float** d_ptr, long long* frame_stride_floats) {
+    DODT_REQUIRE(ex && d_ptr && frame_stride_floats, "dodt_extractor_input: NULL argument");
+    const Buffer& x0 = ex->buf[X0];
+    *d_ptr = x0.ptr + (size_t)ex->pad_top * x0.W * x0.C;
+    *frame_stride_floats = (long long)x0.frame_floats();
+    return DODT_OK;
+}
+
+int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_out,
+                           float* d_bottleneck_out) {
+    DODT_REQUIRE(ex && d_feat_out, "dodt_extractor_forward: NULL argument");
+    for (const Layer& l : ex->layers)
+        DODT_REQUIRE(l.loaded, "dodt_extractor_forward: weights of layer %s not set",
+                     l.name.c_str());
+    DODT_REQUIRE(!d_bottleneck_out || ex->bneck_loaded,
+                 "dodt_extractor_forward: bottleneck weights not set");
+    hipStream_t s = ex->ctx->stream;
+    const Buffer& x0 = ex->buf[X0];
+    float* own_in = x0.ptr + (size_t)ex->pad_top * x0.W * x0.C;
+    if (d_in && d_in != own_in) {
+        const long long n4 = (long long)ex->in_h * ex->in_w * ex->in_c / 4;
+        DODT_REQUIRE(((long long)ex->in_h * ex->in_w * ex->in_c) % 4 == 0, "input not float4-sized");
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n4 * ex->batch + 255) / 256)),
+                           dim3(256), 0, s, reinterpret_cast<const float4*>(d_in),
+                           reinterpret_cast<float4*>(own_in), n4, n4,
+                           (long long)x0.frame_floats() / 4, ex->batch);
+        DODT_LAUNCH_CHECK();
+    }
+    int rc;
+    auto L = [&](const char* n) -> const Layer& { return ex->layers[find_layer(ex, n)]; };
+#define RUN(name)                                           \
+    if ((rc = run_layer(ex, L(name), nullptr, 0, 0))) return rc;
+    RUN("conv1_1"); RUN("conv1_2");
+    if ((rc = run_pool(ex, CAT1, P1))) return rc;
+    RUN("conv2_1"); RUN("conv2_2");
+    if ((rc = run_pool(ex, CAT2, P2))) return rc;
+    RUN("conv3_1"); RUN("conv3_2"); RUN("conv3_3");
+    if ((rc = run_pool(ex, CAT3, P3))) return rc;
+    RUN("conv4_1"); RUN("conv4_2"); RUN("conv4_3");
+    RUN("upconv3"); RUN("pyramid_fusion3");
+    RUN("upconv2"); RUN("pyramid_fusion2");
+    RUN("upconv1");
+#undef RUN
+    // last layer writes straight into the caller's buffer, pad rows sliced off
+    if ((rc = run_layer(ex, L("pyramid_fusion1"), d_feat_out, ex->pad_top, ex->in_h))) return rc;
+    if (d_bottleneck_out) {
+        const long long n_pix = (long long)ex->batch * ex->in_h * ex->in_w;
+        hipLaunchKernelGGL(bottleneck32_kernel, dim3((unsigned)((n_pix * 8 + 255) / 256)),
+                           dim3(256), 0, s, d_feat_out, n_pix, ex->d_bneck_w, ex->bneck_scale,
+                           ex->bneck_shift, d_bottleneck_out);
+        DODT_LAUNCH_CHECK();
+    }
+    return DODT_OK;
+}
+
+int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* dst, int* h,
+                                   int* w, int* c) {
+    DODT_REQUIRE(ex && name, "dodt_extractor_read_activation: NULL argument");
+    const int li = find_layer(ex, name);
+    DODT_REQUIRE(li >= 0, "dodt_extractor_read_activation: unknown layer '%s'", name);
+    const Layer& l = ex->layers[li];
+    const Buffer& b = ex->buf[buffer_for_layer_output(l)];
+    const int oh = l.deconv ? 2 * l.H : l.H, ow = l.deconv ? 2 * l.W : l.W;
+    if (h) *h = oh;
+    if (w) *w = ow;
+    if (c) *c = l.Cout;
+    if (!dst) return DODT_OK;
+    // strided channel slice -> dense host tensor (batch, oh, ow, Cout)
+    DODT_HIP_CHECK(hipStreamSynchronize(ex->ctx->stream));
+    DODT_HIP_CHECK(hipMemcpy2D(dst, (size_t)l.Cout * sizeof(float), b.ptr + l.dst_coff,
+                               (size_t)b.C * sizeof(float), (size_t)l.Cout * sizeof(float),
+                               (size_t)ex->batch * oh * ow, hipMemcpyDeviceToHost));
+    return DODT_OK;
+}
+
+double dodt_extractor_flops(const dodt_extractor* ex) {
+    if (!ex) return 0.0;
+    double f = 0.0;  // 2*M*N*K per layer; transposed convs counted on input pixels
+    for (const Layer& l : ex->layers)
+        f += 2.0 * l.H * l.W * (double)l.Cout * 9.0 * l.real_cin * ex->batch;
+    return f;
+}
+
+}  // extern "C"

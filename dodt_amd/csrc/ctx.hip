@@ -1,0 +1,153 @@
+// Context, device memory and the HIP-event stopwatch of libdodt_hip.so.
+#include "common.h"
+
+namespace dodt {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int Scratch::reserve(size_t need) {
+    if (need <= bytes) return DODT_OK;
+    if (ptr) {
+        DODT_HIP_CHECK(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+    }
+    size_t want = align_up(need + need / 4, 256);
+    DODT_HIP_CHECK(hipMalloc(&ptr, want));
+    bytes = want;
+    return DODT_OK;
+}
+
+void Scratch::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+}  // namespace dodt
+
+extern "C" {
+
+int dodt_version(void) { return 1; }
+
+const char* dodt_last_error(void) { return dodt::g_last_error.c_str(); }
+
+static int ctx_create(int device_id, hipStream_t stream, bool external, dodt_ctx** out) {
+    DODT_REQUIRE(out != nullptr, "dodt_ctx_create: out is NULL");
+    int ndev = 0;
+    DODT_HIP_CHECK(hipGetDeviceCount(&ndev));
+    DODT_REQUIRE(device_id >= 0 && device_id < ndev,
+                 "dodt_ctx_create: device %d out of range (%d visible)", device_id, ndev);
+    DODT_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    DODT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    dodt_ctx* c = new dodt_ctx();
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    if (external) {
+        c->stream = stream;
+        c->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            dodt::set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return DODT_ERR_HIP;
+        }
+        c->owns_stream = true;
+    }
+    (void)hipEventCreate(&c->ev_start);
+    (void)hipEventCreate(&c->ev_stop);
+    *out = c;
+    return DODT_OK;
+}
+
+int dodt_ctx_create(int device_id, dodt_ctx** out) {
+    return ctx_create(device_id, nullptr, false, out);
+}
+
+int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out) {
+    return ctx_create(device_id, (hipStream_t)hip_stream, true, out);
+}
+
+int dodt_ctx_destroy(dodt_ctx* ctx) {
+    if (!ctx) return DODT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->vox_ws.release();
+    ctx->anchor_ws.release();
+    ctx->nms_ws.release();
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DODT_OK;
+}
+
+int dodt_ctx_sync(dodt_ctx* ctx) {
+    DODT_REQUIRE(ctx, "dodt_ctx_sync: ctx is NULL");
+    DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_malloc(dodt_ctx* ctx, size_t bytes, void** d_out) {
+    DODT_REQUIRE(ctx && d_out, "dodt_malloc: NULL argument");
+    DODT_HIP_CHECK(hipSetDevice(ctx->device));
+    DODT_HIP_CHECK(hipMalloc(d_out, bytes ? bytes : 1));
+    return DODT_OK;
+}
+
+int dodt_free(dodt_ctx* ctx, void* d_ptr) {
+    DODT_REQUIRE(ctx, "dodt_free: ctx is NULL");
+    if (d_ptr) DODT_HIP_CHECK(hipFree(d_ptr));
+    return DODT_OK;
+}
+
+int dodt_memcpy_h2d(dodt_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    DODT_REQUIRE(ctx && (bytes == 0 || (d_dst && src)), "dodt_memcpy_h2d: NULL argument");
+    if (bytes == 0) return DODT_OK;
+    DODT_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the source is pageable host memory owned by the caller: finish before return
+    DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_memcpy_d2h(dodt_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    DODT_REQUIRE(ctx && (bytes == 0 || (dst && d_src)), "dodt_memcpy_d2h: NULL argument");
+    if (bytes == 0) return DODT_OK;
+    DODT_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes) {
+    DODT_REQUIRE(ctx && (bytes == 0 || d_dst), "dodt_memset: NULL argument");
+    if (bytes == 0) return DODT_OK;
+    DODT_HIP_CHECK(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_timer_start(dodt_ctx* ctx) {
+    DODT_REQUIRE(ctx, "dodt_timer_start: ctx is NULL");
+    DODT_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_timer_stop(dodt_ctx* ctx, float* ms_out) {
+    DODT_REQUIRE(ctx && ms_out, "dodt_timer_stop: NULL argument");
+    DODT_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
+    DODT_HIP_CHECK(hipEventSynchronize(ctx->ev_stop));
+    DODT_HIP_CHECK(hipEventElapsedTime(ms_out, ctx->ev_start, ctx->ev_stop));
+    return DODT_OK;
+}
+
+}  // extern "C"

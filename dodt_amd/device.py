@@ -1,0 +1,115 @@
+"""Device context and device arrays over the C-ABI (no PyTorch)."""
+import ctypes as C
+
+import numpy as np
+
+from dodt_amd import _lib
+
+
+class DeviceArray(object):
+    """A typed, shaped view of device memory.  Owns the allocation unless it
+    wraps an external pointer (e.g. a torch tensor's data_ptr())."""
+
+    def __init__(self, ctx, shape, dtype, ptr=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._owns = ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            _lib.check(ctx.lib.dodt_malloc(ctx.handle, self.nbytes, C.byref(p)),
+                       'dodt_malloc')
+            ptr = p.value
+        self.ptr = ptr
+
+    def offset(self, nbytes, shape, dtype=None):
+        """View starting `nbytes` into this array (no ownership)."""
+        return DeviceArray(self.ctx, shape, dtype or self.dtype,
+                           ptr=self.ptr + int(nbytes))
+
+    def upload(self, host):
+        a = np.ascontiguousarray(host, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError('upload: %d bytes into a %d-byte device array'
+                             % (a.nbytes, self.nbytes))
+        _lib.check(self.ctx.lib.dodt_memcpy_h2d(
+            self.ctx.handle, self.ptr, a.ctypes.data, a.nbytes), 'h2d')
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        _lib.check(self.ctx.lib.dodt_memcpy_d2h(
+            self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes), 'd2h')
+        return out
+
+    def zero(self):
+        _lib.check(self.ctx.lib.dodt_memset(self.ctx.handle, self.ptr, 0,
+                                            self.nbytes), 'memset')
+        return self
+
+    def free(self):
+        if self._owns and self.ptr:
+            self.ctx.lib.dodt_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One per GPU per process (include/dodt_hip.h conventions)."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self.lib.dodt_ctx_create(int(device_id), C.byref(h))
+        else:
+            rc = self.lib.dodt_ctx_create_on_stream(int(device_id),
+                                                    C.c_void_p(int(stream)),
+                                                    C.byref(h))
+        _lib.check(rc, 'dodt_ctx_create')
+        self.handle = h
+        self.device_id = int(device_id)
+
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype).zero()
+
+    def array(self, host, dtype=None):
+        host = np.asarray(host)
+        return DeviceArray(self, host.shape, dtype or host.dtype).upload(host)
+
+    def wrap(self, ptr, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype, ptr=int(ptr))
+
+    def sync(self):
+        _lib.check(self.lib.dodt_ctx_sync(self.handle), 'dodt_ctx_sync')
+
+    def timer_start(self):
+        _lib.check(self.lib.dodt_timer_start(self.handle), 'timer_start')
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.check(self.lib.dodt_timer_stop(self.handle, C.byref(ms)), 'timer_stop')
+        return ms.value
+
+    def close(self):
+        if self.handle:
+            self.lib.dodt_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_default = {}
+
+
+def default_context(device_id=0):
+    if device_id not in _default:
+        _default[device_id] = Context(device_id)
+    return _default[device_id]

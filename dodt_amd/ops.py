@@ -1,0 +1,125 @@
+"""Thin device-level wrappers: DeviceArray in, DeviceArray out, one C-ABI call each.
+
+These are what the frame-pair pipeline is made of; the avod.core-shaped host API
+in dodt_amd/core/ wraps them with numpy upload/download.
+"""
+import ctypes as C
+
+import numpy as np
+
+from dodt_amd import _lib
+
+
+def _arr(ctype, values):
+    values = [float(v) for v in np.asarray(values, dtype=np.float64).reshape(-1)]
+    return (ctype * len(values))(*values)
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ptr)
+
+
+def make_bev_params(cfg, velo_to_cam=None, p2=None, im_wh=None,
+                    point_format=_lib.PTS_VELO_XYZI, ground_plane=None,
+                    area_extents=None, voxel_size=None):
+    """dodt_bev_params from a config dict (dodt_amd.config) and calibration."""
+    bp = _lib.BevParams()
+    bp.point_format = point_format
+    bp.num_slices = int(cfg['num_slices'])
+    m = np.zeros(12) if velo_to_cam is None else \
+        np.asarray(velo_to_cam, dtype=np.float64).reshape(-1)[:12]
+    p = np.zeros(12) if p2 is None else np.asarray(p2, dtype=np.float64).reshape(-1)
+    bp.velo_to_cam = (C.c_double * 12)(*m)
+    bp.p2 = (C.c_double * 12)(*p)
+    bp.im_w, bp.im_h = (0.0, 0.0) if im_wh is None else (float(im_wh[0]), float(im_wh[1]))
+    plane = cfg['ground_plane'] if ground_plane is None else ground_plane
+    bp.plane = (C.c_double * 4)(*[float(v) for v in plane])
+    ext = cfg['area_extents'] if area_extents is None else area_extents
+    bp.extents = (C.c_double * 6)(*[float(v) for v in np.asarray(ext).reshape(-1)])
+    bp.voxel_size = float(cfg['voxel_size'] if voxel_size is None else voxel_size)
+    bp.height_lo = float(cfg['height_lo'])
+    bp.height_hi = float(cfg['height_hi'])
+    bp.occ_lo = float(cfg['anchor_filter_lo'])
+    bp.occ_hi = float(cfg['anchor_filter_hi'])
+    return bp
+
+
+def bev_slices(ctx, d_points, n_points, bev_params, d_bev_out, d_occ_bits=None):
+    _lib.check(ctx.lib.dodt_bev_slices(ctx.handle, _p(d_points), int(n_points),
+                                       C.byref(bev_params), _p(d_bev_out),
+                                       _p(d_occ_bits)), 'dodt_bev_slices')
+
+
+def bev_status(ctx):
+    f = C.c_int()
+    _lib.check(ctx.lib.dodt_bev_status(ctx.handle, C.byref(f)), 'dodt_bev_status')
+    return f.value
+
+
+def anchor_filter(ctx, d_occ_bits, nx, nz, d_cells, n_anchors, d_keep_idx, d_count,
+                  density_threshold=1):
+    _lib.check(ctx.lib.dodt_anchor_filter(
+        ctx.handle, _p(d_occ_bits), int(nx), int(nz), _p(d_cells), int(n_anchors),
+        int(density_threshold), _p(d_keep_idx), _p(d_count)), 'dodt_anchor_filter')
+
+
+def project_anchors_f64(ctx, d_anchors, d_idx, n, d_n, bev_extents, p2, im_wh,
+                        d_bev_norm=None, d_img_norm=None, d_anchors_f32=None):
+    _lib.check(ctx.lib.dodt_project_anchors_f64(
+        ctx.handle, _p(d_anchors), _p(d_idx), int(n), _p(d_n),
+        _arr(C.c_double, bev_extents), _arr(C.c_double, p2),
+        float(im_wh[0]), float(im_wh[1]), _p(d_bev_norm), _p(d_img_norm),
+        _p(d_anchors_f32)), 'dodt_project_anchors_f64')
+
+
+def project_anchors_f32(ctx, d_anchors, n, d_n, bev_extents, p2, im_wh,
+                        d_bev=None, d_bev_norm_tf=None, d_img_norm_tf=None):
+    _lib.check(ctx.lib.dodt_project_anchors_f32(
+        ctx.handle, _p(d_anchors), int(n), _p(d_n), _arr(C.c_float, bev_extents),
+        _arr(C.c_float, p2), float(im_wh[0]), float(im_wh[1]), _p(d_bev),
+        _p(d_bev_norm_tf), _p(d_img_norm_tf)), 'dodt_project_anchors_f32')
+
+
+def img_preprocess(ctx, d_img_u8, in_hw, out_hw, out_c, mean_rgb, d_out):
+    _lib.check(ctx.lib.dodt_img_preprocess(
+        ctx.handle, _p(d_img_u8), int(in_hw[0]), int(in_hw[1]), int(out_hw[0]),
+        int(out_hw[1]), int(out_c), _arr(C.c_float, mean_rgb), _p(d_out)),
+        'dodt_img_preprocess')
+
+
+def crop_and_resize(ctx, d_image, hwc, d_boxes, n, d_n, crop_hw, d_out):
+    _lib.check(ctx.lib.dodt_crop_and_resize(
+        ctx.handle, _p(d_image), int(hwc[0]), int(hwc[1]), int(hwc[2]), _p(d_boxes),
+        int(n), _p(d_n), int(crop_hw[0]), int(crop_hw[1]), _p(d_out)),
+        'dodt_crop_and_resize')
+
+
+def nms(ctx, d_boxes, d_scores, n, d_n, max_out, iou_threshold, d_sel, d_count):
+    _lib.check(ctx.lib.dodt_nms(
+        ctx.handle, _p(d_boxes), _p(d_scores), int(n), _p(d_n), int(max_out),
+        float(iou_threshold), _p(d_sel), _p(d_count)), 'dodt_nms')
+
+
+def offset_to_anchor(ctx, d_anchors, d_offsets, n, d_n, d_out):
+    _lib.check(ctx.lib.dodt_offset_to_anchor(
+        ctx.handle, _p(d_anchors), _p(d_offsets), int(n), _p(d_n), _p(d_out)),
+        'dodt_offset_to_anchor')
+
+
+def softmax_fg(ctx, d_logits, n, d_n, d_scores):
+    _lib.check(ctx.lib.dodt_softmax_fg(
+        ctx.handle, _p(d_logits), int(n), _p(d_n), _p(d_scores)), 'dodt_softmax_fg')
+
+
+def gather_rows(ctx, d_src, width, d_idx, n, d_n, d_out):
+    _lib.check(ctx.lib.dodt_gather_rows(
+        ctx.handle, _p(d_src), int(width), _p(d_idx), int(n), _p(d_n), _p(d_out)),
+        'dodt_gather_rows')
+
+
+def box_4c_decode(ctx, d_top_anchors, d_offsets, n, d_n, plane, bev_extents,
+                  d_boxes_3d=None, d_pred_anchors=None, d_bev_tf=None):
+    _lib.check(ctx.lib.dodt_box_4c_decode(
+        ctx.handle, _p(d_top_anchors), _p(d_offsets), int(n), _p(d_n),
+        _arr(C.c_float, plane), _arr(C.c_float, bev_extents), _p(d_boxes_3d),
+        _p(d_pred_anchors), _p(d_bev_tf)), 'dodt_box_4c_decode')

@@ -1,0 +1,104 @@
+"""Deterministic synthetic inputs and weights of the shapes the hot path sees
+(SURVEY.md section 8d).  No dataset or checkpoint ships with the reference, so
+benchmarks and parity tests run on these."""
+import numpy as np
+
+# avod/tests/datasets/Kitti/tracking/training/calib/0000.txt (numbers only)
+P2 = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01],
+               [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01],
+               [0.0, 0.0, 1.0, 2.745884e-03]])
+R0_RECT = np.array([[9.999239e-01, 9.837760e-03, -7.445048e-03],
+                    [-9.869795e-03, 9.999421e-01, -4.278459e-03],
+                    [7.402527e-03, 4.351614e-03, 9.999631e-01]])
+TR_VELO_TO_CAM = np.array(
+    [[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
+     [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
+     [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01]])
+IMAGE_WH = (1242, 375)
+
+PYRAMID_CHANNELS = {
+    'conv1_1': (None, 32), 'conv1_2': (32, 32),
+    'conv2_1': (32, 64), 'conv2_2': (64, 64),
+    'conv3_1': (64, 128), 'conv3_2': (128, 128), 'conv3_3': (128, 128),
+    'conv4_1': (128, 256), 'conv4_2': (256, 256), 'conv4_3': (256, 256),
+    'upconv3': (256, 128), 'pyramid_fusion3': (256, 64),
+    'upconv2': (64, 64), 'pyramid_fusion2': (128, 32),
+    'upconv1': (32, 32), 'pyramid_fusion1': (64, 32),
+}
+PYRAMID_LAYERS = list(PYRAMID_CHANNELS.keys())
+TRANSPOSED = ('upconv3', 'upconv2', 'upconv1')
+
+
+def velo_to_cam(r0_rect=R0_RECT, tr=TR_VELO_TO_CAM):
+    """(3,4) = (R0_rect padded . Tr_velo_to_cam padded)[0:3], float64
+    (wavedata/.../calib_utils.py:502-519)."""
+    r0 = np.zeros((4, 4)); r0[:3, :3] = r0_rect; r0[3, 3] = 1
+    t = np.zeros((4, 4)); t[:3, :4] = tr; t[3, 3] = 1
+    return np.dot(r0, t)[:3]
+
+
+def frame_seed(seq, frame):
+    return 0xD0D7 + 1000 * seq + frame
+
+
+def lidar_frame(seq, frame, n_points=120000, n_boxes=12):
+    """(N,4) float32 xyzi in the velodyne frame: 64 rings, ground-plane returns
+    capped at 80 m, 12 % of returns on random car-sized boxes."""
+    rng = np.random.default_rng(frame_seed(seq, frame))
+    az = rng.uniform(-np.pi, np.pi, n_points)
+    ring = rng.integers(0, 64, n_points)
+    el = np.deg2rad(-24.8 + (26.8 / 63.0) * ring) + rng.normal(0, 1e-3, n_points)
+    rng_ground = np.where(np.sin(el) < -1e-3, 1.73 / np.maximum(-np.sin(el), 1e-3), 80.0)
+    r = np.minimum(rng_ground, 80.0) * rng.uniform(0.98, 1.0, n_points)
+    x = r * np.cos(el) * np.cos(az)
+    y = r * np.cos(el) * np.sin(az)
+    z = r * np.sin(el)
+    k = int(0.12 * n_points)
+    centres = np.stack([rng.uniform(5, 65, n_boxes), rng.uniform(-30, 30, n_boxes)], 1)
+    which = rng.integers(0, n_boxes, k)
+    x[:k] = centres[which, 0] + rng.uniform(-2.0, 2.0, k)
+    y[:k] = centres[which, 1] + rng.uniform(-0.85, 0.85, k)
+    z[:k] = -1.73 + rng.uniform(0.0, 1.5, k)
+    inten = rng.uniform(0, 1, n_points)
+    return np.stack([x, y, z, inten], 1).astype(np.float32)
+
+
+def image_frame(seq, frame, wh=IMAGE_WH):
+    rng = np.random.default_rng(frame_seed(seq, frame) + 7)
+    return rng.integers(0, 256, size=(wh[1], wh[0], 3), dtype=np.uint8)
+
+
+def pyramid_params(in_ch, seed=42):
+    """Per-layer rng(seed + layer index): w ~ N(0, 2/(9 Cin)) in TF layout
+    (HWIO; HWOI for the transposed convs), BN mean 0 / var 1 / beta ~ N(0, .01)."""
+    params = {}
+    for li, name in enumerate(PYRAMID_LAYERS):
+        cin, cout = PYRAMID_CHANNELS[name]
+        cin = in_ch if cin is None else cin
+        rng = np.random.default_rng(seed + li)
+        std = np.sqrt(2.0 / (9 * cin))
+        shape = (3, 3, cout, cin) if name in TRANSPOSED else (3, 3, cin, cout)
+        params[name] = dict(
+            w=rng.normal(0, std, size=shape).astype(np.float32),
+            beta=rng.normal(0, 0.01, size=cout).astype(np.float32),
+            mean=np.zeros(cout, dtype=np.float32),
+            var=np.ones(cout, dtype=np.float32))
+    rng = np.random.default_rng(seed + 100)
+    params['bottleneck'] = dict(
+        w=rng.normal(0, np.sqrt(2.0 / 32), size=(1, 1, 32, 1)).astype(np.float32),
+        beta=rng.normal(0, 0.01, size=1).astype(np.float32),
+        mean=np.zeros(1, dtype=np.float32), var=np.ones(1, dtype=np.float32))
+    return params
+
+
+def head_outputs(seq, frame, n_anchors, n_proposals):
+    """Seeded stand-ins for the dense heads (not on the path
+    yet): RPN objectness logits (A,2) + offsets (A,6); stage-2 class logits
+    (P,2), box_4c offsets (P,10), angle vectors (P,2)."""
+    rng = np.random.default_rng(frame_seed(seq, frame) + 13)
+    return dict(
+        rpn_logits=rng.normal(0, 2.0, size=(n_anchors, 2)).astype(np.float32),
+        rpn_offsets=rng.normal(0, 0.1, size=(n_anchors, 6)).astype(np.float32),
+        cls_logits=rng.normal(0, 2.0, size=(n_proposals, 2)).astype(np.float32),
+        offsets_4c=rng.normal(0, 0.1, size=(n_proposals, 10)).astype(np.float32),
+        angle_vectors=rng.normal(0, 1.0, size=(n_proposals, 2)).astype(np.float32))

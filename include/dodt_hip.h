@@ -1,0 +1,226 @@
+/*
+ * dodt_hip.h -- C ABI of libdodt_hip.so, the MI355X (gfx950) hot path of DODT/AVOD.
+ *
+ * The reference has no FFI on this path: its seams are ordinary Python call
+ * signatures.  Each entry point below names the reference
+ * call it stands behind (paths relative to the reference root).  The ABI follows
+ * the one C precedent in the reference, wavedata's integralImage3D
+ * (wavedata/wavedata/tools/core/lib/src/integral_images_3d.cpp:66-77, bound in
+ * wavedata/wavedata/tools/core/integral_image.py:22-23,96-122): extern "C",
+ * caller-allocated outputs, plain pointers and sizes, no ownership transfer --
+ * except that every call returns an int status (0 = ok) and the message is
+ * available from dodt_last_error() instead of failing silently.
+ *
+ * Conventions
+ *   - One dodt_ctx per GPU per process; it owns one HIP stream and the scratch
+ *     memory.  Calls on a ctx are serialised by the caller (the reference is
+ *     single threaded, one sess.run at a time).
+ *   - Every pointer argument whose name starts with d_ is DEVICE memory
+ *     (dodt_malloc, or any hipMalloc'ed / torch-allocated buffer); all other
+ *     pointers are host memory, read before the call returns.
+ *   - Compute calls are asynchronous on the ctx stream; dodt_ctx_sync() or a
+ *     dodt_memcpy_d2h() makes results visible to the host.
+ *   - Image-like tensors are NHWC float32 with the batch dimension dropped,
+ *     exactly the layout of the reference's TF placeholders.
+ *   - No call retains a caller pointer past its return (weights are copied).
+ */
+#ifndef DODT_HIP_H
+#define DODT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DODT_OK 0
+#define DODT_ERR_INVALID 1   /* bad argument (the reference raises ValueError) */
+#define DODT_ERR_HIP 2       /* a HIP runtime call failed                       */
+#define DODT_ERR_UNSUPPORTED 3
+
+typedef struct dodt_ctx dodt_ctx;
+
+/* ---- context, memory --------------------------------------------------- */
+int dodt_version(void);
+const char* dodt_last_error(void);            /* thread-local, never NULL */
+int dodt_ctx_create(int device_id, dodt_ctx** out);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out);
+int dodt_ctx_destroy(dodt_ctx* ctx);
+int dodt_ctx_sync(dodt_ctx* ctx);
+int dodt_malloc(dodt_ctx* ctx, size_t bytes, void** d_out);
+int dodt_free(dodt_ctx* ctx, void* d_ptr);
+int dodt_memcpy_h2d(dodt_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int dodt_memcpy_d2h(dodt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes);
+
+/* HIP-event stopwatch on the ctx stream: start; ...launches...; stop -> ms
+ * (stop waits for the stream). */
+int dodt_timer_start(dodt_ctx* ctx);
+int dodt_timer_stop(dodt_ctx* ctx, float* ms_out);
+
+/* ---- a0-a3: BEV voxel/slice generator --------------------------------------
+ * Stands behind BevSlices.generate_bev (avod/core/bev_generators/bev_slices.py:
+ * 33-150) and, with DODT_PTS_VELO_XYZI, also the point path in front of it:
+ * lidar_to_cam_frame + z>0 + image-frustum filter
+ * (wavedata/.../core/calib_utils.py:484-523, obj_detection/tracking_utils.py:
+ * 117-150).  All geometry is evaluated in float64 like the reference. */
+#define DODT_PTS_VELO_XYZI 0 /* d_points = (N,4) float32 x,y,z,intensity, velodyne frame */
+#define DODT_PTS_CAM_3XN 1   /* d_points = (3,N) float64 rectified camera frame          */
+
+typedef struct dodt_bev_params {
+    int32_t point_format;     /* DODT_PTS_*                                         */
+    int32_t num_slices;       /* height slices (5); output depth = num_slices + 1   */
+    double velo_to_cam[12];   /* (3,4) row major = (R0_rect . Tr_velo_to_cam)[0:3]  */
+    double p2[12];            /* (3,4) camera matrix                                 */
+    double im_w, im_h;        /* frustum: 0 < u < im_w, 0 < v < im_h (strict)       */
+    double plane[4];          /* ground plane a,b,c,d                               */
+    double extents[6];        /* x0,x1,y0,y1,z0,z1 (strict on both sides)           */
+    double voxel_size;        /* float32-rounded 0.1 as python sees it (F7)         */
+    double height_lo, height_hi;
+    double occ_lo, occ_hi;    /* slice of the anchor-filter occupancy grid (0.2,2.0) */
+} dodt_bev_params;
+
+/* d_bev_out: (Z, X, num_slices+1) float32, Z = 700 rows, X = 800 cols for the
+ *            KITTI extents; out[r, c, s] = map_s[c, Z-1-r] like the reference.
+ * d_occ_bits_out (may be NULL): occupancy of the [occ_lo, occ_hi) slice as a
+ *            bit grid, Z rows of ceil(X/32) uint32 words, bit (x & 31) of word
+ *            [z * ceil(X/32) + (x >> 5)]; feeds dodt_anchor_filter.
+ * Returns DODT_ERR_INVALID when X*Z cells or the y-bin range do not fit the
+ * packed 32-bit key (n_points >= 2^25 or more than 127 y-bins). */
+int dodt_bev_slices(dodt_ctx* ctx, const void* d_points, int n_points,
+                    const dodt_bev_params* params, float* d_bev_out,
+                    uint32_t* d_occ_bits_out);
+/* Waits for the stream and reports whether the last dodt_bev_slices on this ctx
+ * met a point whose cell lies outside the grid (*flags & 1) -- the case in which
+ * the reference raises ValueError("Extents are smaller than ...")
+ * (voxel_grid_2d.py:130-138) -- or overflowed its work list (*flags & 2). */
+int dodt_bev_status(dodt_ctx* ctx, int* flags);
+
+/* ---- a4: empty-anchor filter -------------------------------------------------
+ * Stands behind get_empty_anchor_filter_2d (avod/core/anchor_filter.py:64-119)
+ * + IntegralImage2D.query (wavedata/.../core/integral_image_2d.py:39-87).
+ * d_anchor_cells: (n_anchors,4) int32 [x1,z1,x2,z2] grid indices produced on the
+ *   host once per configuration exactly as the reference does (float32 corners,
+ *   float32 division, int32 truncation, clip to [0,X] / [0,Z]).
+ * d_keep_idx_out: (n_anchors) int32, first *count entries = kept anchor indices in
+ *   ascending (generator) order.  d_count_out: (1) int32. */
+int dodt_anchor_filter(dodt_ctx* ctx, const uint32_t* d_occ_bits, int nx, int nz,
+                       const int32_t* d_anchor_cells, int n_anchors,
+                       int density_threshold, int32_t* d_keep_idx_out,
+                       int32_t* d_count_out);
+
+/* ---- a5/a6: anchor projection --------------------------------------------------
+ * project_to_bev (avod/core/anchor_projector.py:13-69), project_to_image_space
+ * (:72-156, numpy branch, float64 in / float32 out) and the [y1,x1,y2,x2] reorder
+ * (:254-273; models/dt_rpn_model.py:983-985).
+ * d_anchors: (n_total,6) float64 table; d_idx (may be NULL = identity): (n) int32
+ * rows to project; *d_n (may be NULL): device count overriding n (<= n).
+ * Outputs (n,4) float32 normalised boxes in TF order [y1,x1,y2,x2]. */
+int dodt_project_anchors_f64(dodt_ctx* ctx, const double* d_anchors,
+                             const int32_t* d_idx, int n, const int32_t* d_n,
+                             const double bev_extents[4], const double p2[12],
+                             double im_w, double im_h, float* d_bev_norm_out,
+                             float* d_img_norm_out, float* d_anchors_f32_out);
+
+/* TF-branch twins, float32 throughout (models/dt_avod_model.py:170-206):
+ * project_to_bev + tf_project_to_image_space (anchor_projector.py:159-251).
+ * d_bev_out (n,4) metres [x1,z1,x2,z2] (may be NULL), d_bev_norm_tf_out and
+ * d_img_norm_tf_out (n,4) in TF order. */
+int dodt_project_anchors_f32(dodt_ctx* ctx, const float* d_anchors, int n,
+                             const int32_t* d_n, const float bev_extents[4],
+                             const float p2[12], float im_w, float im_h,
+                             float* d_bev_out, float* d_bev_norm_tf_out,
+                             float* d_img_norm_tf_out);
+
+/* ---- a7: image preprocessing ---------------------------------------------------
+ * ImgFeatureExtractor.preprocess_input (avod/core/feature_extractors/
+ * img_feature_extractor.py:16-35): legacy bilinear resize + per-channel mean
+ * subtraction.  d_img_u8: (in_h,in_w,3) uint8 RGB.  d_out: (out_h,out_w,out_c)
+ * float32 with out_c >= 3; channels >= 3 are written as 0 (the conv kernels
+ * want an even channel count). */
+int dodt_img_preprocess(dodt_ctx* ctx, const uint8_t* d_img_u8, int in_h, int in_w,
+                        int out_h, int out_w, int out_c, const float mean_rgb[3],
+                        float* d_out);
+
+/* ---- a8-a10: feature extractors ---------------------------------------------------
+ * Stands behind feature_extractor_builder.get_extractor(cfg).build(...)
+ * (avod/core/feature_extractors/bev_vgg_pyramid.py:30-178, img_vgg_pyramid.py:
+ * 30-177) plus the 1x1 bottleneck (models/dt_rpn_model.py:298-322). */
+typedef struct dodt_extractor dodt_extractor;
+#define DODT_EXTRACTOR_VGG_PYR 0
+/* in_c: channels of the input tensor as stored (6 for BEV; 4 for the padded
+ * image); pad_top: zero rows added on top (4 for BEV 700->704, 0 for images);
+ * batch: frames processed per forward call (2 = both frames of a pair). */
+int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
+                          int pad_top, int batch, dodt_extractor** out);
+int dodt_extractor_destroy(dodt_extractor* ex);
+/* One conv layer: name as in the TF variable scope ("conv1_1" ... "conv4_3",
+ * "upconv3", "pyramid_fusion3", ..., "bottleneck").  w: HWIO (kh,kw,cin,cout)
+ * for conv2d, (kh,kw,cout,cin) for conv2d_transpose, as TF stores them.
+ * beta/mean/var: slim.batch_norm variables (no gamma, eps = 1e-3).  Host memory. */
+int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* w,
+                             int kh, int kw, int c_a, int c_b, const float* beta,
+                             const float* mean, const float* var);
+/* Zero-copy input: *d_ptr = where frame 0 of the (batch, in_h, in_w, in_c) input
+ * lives inside the extractor (frame f at + f * *frame_stride_floats).  A producer
+ * that writes there (e.g. dodt_bev_slices) can pass d_in = NULL to forward. */
+int dodt_extractor_input(dodt_extractor* ex, float** d_ptr, long long* frame_stride_floats);
+/* d_in: (batch, in_h, in_w, in_c) or NULL (see above); d_feat_out: (batch, in_h, in_w, 32);
+ * d_bottleneck_out (may be NULL): (batch, in_h, in_w, 1). */
+int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_out,
+                           float* d_bottleneck_out);
+/* Debug/test access to an intermediate activation by layer name: copies the
+ * (batch, h, w, c) float32 tensor to host memory `dst` (NULL to query shape). */
+int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* dst,
+                                   int* h, int* w, int* c);
+/* FLOPs of one forward call (2*M*N*K summed over conv layers, all frames). */
+double dodt_extractor_flops(const dodt_extractor* ex);
+
+/* ---- a11: ROI crop ------------------------------------------------------------------
+ * tf.image.crop_and_resize(image, boxes, box_ind=0, crop_size) call sites
+ * models/dt_rpn_model.py:418-428 and models/dt_avod_model.py:253-273.
+ * d_image (H,W,C); d_boxes (n,4) [y1,x1,y2,x2] normalised; d_out (n,ch,cw,C);
+ * *d_n (may be NULL) overrides n on the device. */
+int dodt_crop_and_resize(dodt_ctx* ctx, const float* d_image, int H, int W, int C,
+                         const float* d_boxes, int n, const int32_t* d_n, int crop_h,
+                         int crop_w, float* d_out);
+
+/* ---- a13: NMS -------------------------------------------------------------------------
+ * tf.image.non_max_suppression(boxes, scores, max_output_size, iou_threshold),
+ * call sites models/dt_rpn_model.py:587-591 and models/dt_avod_model.py:606-613.
+ * Candidate order is (score descending, index ascending) -- TF leaves ties
+ * unspecified.  d_sel_out: (max_out) int32 selected ORIGINAL indices in score
+ * order; d_count_out: (1) int32.  *d_n (may be NULL) overrides n. */
+int dodt_nms(dodt_ctx* ctx, const float* d_boxes, const float* d_scores, int n,
+             const int32_t* d_n, int max_out, float iou_threshold, int32_t* d_sel_out,
+             int32_t* d_count_out);
+
+/* ---- a12/a14: box encoders (TF branch, float32) ------------------------------------------ */
+/* anchor_encoder.offset_to_anchor (avod/core/anchor_encoder.py:99-150) */
+int dodt_offset_to_anchor(dodt_ctx* ctx, const float* d_anchors, const float* d_offsets,
+                          int n, const int32_t* d_n, float* d_out);
+/* 2-way softmax, column 1 (models/dt_rpn_model.py:581-584) */
+int dodt_softmax_fg(dodt_ctx* ctx, const float* d_logits2, int n, const int32_t* d_n,
+                    float* d_scores_out);
+/* out[i] = src[idx[i]] rows of `width` floats (tf.gather call sites
+ * dt_rpn_model.py:593-597, dt_avod_model.py:616-640) */
+int dodt_gather_rows(dodt_ctx* ctx, const float* d_src, int width, const int32_t* d_idx,
+                     int n, const int32_t* d_n, float* d_out);
+/* Stage-2 decode (models/dt_avod_model.py:464-469,575-603):
+ *   anchors_to_box_3d(fix_lw) -> tf_box_3d_to_box_4c -> + offsets ->
+ *   tf_box_4c_to_box_3d -> tf_box_3d_to_anchor -> project_to_bev (metres) ->
+ *   reorder.  (avod/core/box_3d_encoder.py:188-322, box_4c_encoder.py:85-165,
+ *   369-484.)  d_top_anchors (n,6), d_offsets (n,10), plane[4] host.
+ * Outputs: d_boxes_3d_out (n,7), d_pred_anchors_out (n,6), d_bev_tf_out (n,4)
+ * [z1,x1,z2,x2] metres (the NMS #2 boxes).  Any output may be NULL. */
+int dodt_box_4c_decode(dodt_ctx* ctx, const float* d_top_anchors, const float* d_offsets,
+                       int n, const int32_t* d_n, const float plane[4],
+                       const float bev_extents[4], float* d_boxes_3d_out,
+                       float* d_pred_anchors_out, float* d_bev_tf_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DODT_HIP_H */

@@ -88,34 +88,3 @@ def bottleneck_1x1(x, p):
     y = (np.asarray(x, dtype=np.float32).reshape(-1, w.shape[0]) @ w)
     y = y.reshape(x.shape[0], x.shape[1], 1)
     return tfops.bn_relu(y, p['beta'], p['mean'], p['var'])
-
-
-def synth_params(in_ch, seed=42, transposed_names=('upconv3', 'upconv2',
-                                                  'upconv1')):
-    """Seeded synthetic weights of the pyramid architecture:
-    per-layer rng(seed + layer index), w ~ N(0, 2/(9*Cin)), BN mean 0, var 1,
-    beta ~ N(0, 0.01).  (Cin, Cout) per layer from the pyramid config 32/64/128/256."""
-    chans = {
-        'conv1_1': (in_ch, 32), 'conv1_2': (32, 32),
-        'conv2_1': (32, 64), 'conv2_2': (64, 64),
-        'conv3_1': (64, 128), 'conv3_2': (128, 128), 'conv3_3': (128, 128),
-        'conv4_1': (128, 256), 'conv4_2': (256, 256), 'conv4_3': (256, 256),
-        'upconv3': (256, 128), 'pyramid_fusion3': (256, 64),
-        'upconv2': (64, 64), 'pyramid_fusion2': (128, 32),
-        'upconv1': (32, 32), 'pyramid_fusion1': (64, 32),
-    }
-    params = {}
-    for li, name in enumerate(pyramid_layer_names()):
-        cin, cout = chans[name]
-        rng = np.random.default_rng(seed + li)
-        std = np.sqrt(2.0 / (9 * cin))
-        if name in transposed_names:
-            w = rng.normal(0, std, size=(3, 3, cout, cin))
-        else:
-            w = rng.normal(0, std, size=(3, 3, cin, cout))
-        params[name] = dict(
-            w=w.astype(np.float32),
-            beta=rng.normal(0, 0.01, size=cout).astype(np.float32),
-            mean=np.zeros(cout, dtype=np.float32),
-            var=np.ones(cout, dtype=np.float32))
-    return params

@@ -1,0 +1,172 @@
+"""HIP ROI crop, NMS and box encoders against the oracle.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from dodt_amd import config as cfg
+from dodt_amd import device, ops, tf_image
+from dodt_amd.core import anchor_encoder as gpu_anchor_encoder
+from dodt_amd.core import box_4c_encoder as gpu_box_4c
+from oracle import boxes as oboxes
+from oracle import tfops
+
+pytestmark = pytest.mark.gpu
+C = cfg.PYRAMID_DODT
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    return device.default_context()
+
+
+def _boxes(rng, n, spread=1.0):
+    """normalised [y1,x1,y2,x2]; a third partly or fully outside the image"""
+    cy, cx = rng.uniform(-0.3, 1.3, n), rng.uniform(-0.3, 1.3, n)
+    h, w = rng.uniform(0.0, 0.3, n) * spread, rng.uniform(0.0, 0.3, n) * spread
+    return np.stack([cy - h, cx - w, cy + h, cx + w], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('hwc,crop', [((44, 50, 32), (7, 7)), ((88, 100, 1), (3, 3)),
+                                      ((30, 40, 25), (7, 7)), ((16, 16, 4), (1, 1)),
+                                      ((9, 11, 3), (2, 5))])
+def test_crop_and_resize_matches_oracle(hwc, crop):
+    rng = np.random.default_rng(hash(hwc) & 0xffff)
+    img = rng.normal(size=hwc).astype(np.float32)
+    b = _boxes(rng, 300)
+    b[0] = [0, 0, 1, 1]
+    b[1] = [0.5, 0.5, 0.5, 0.5]            # degenerate
+    b[2] = [1.0, 1.0, 0.0, 0.0]            # flipped
+    b[3] = [-21.0, -3.0, 24.0, 5.0]        # far outside, like image-space anchors
+    got = tf_image.crop_and_resize(img[None], b, np.zeros(len(b), np.int32), crop)
+    want = tfops.crop_and_resize(img, b, crop[0], crop[1])
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), np.abs(got - want).max()   # unfused fp32: bit exact
+
+
+def test_crop_full_size_properties(ctx):
+    """P = 1024 boxes on a (700,800,32) map: identity box reproduces the map's
+    corners; a box outside the image gives zeros; linear in the image."""
+    rng = np.random.default_rng(3)
+    img = rng.normal(size=(700, 800, 32)).astype(np.float32)
+    b = _boxes(rng, 1024, spread=0.2)
+    b[0] = [0, 0, 1, 1]
+    b[1] = [2, 2, 3, 3]
+    out = tf_image.crop_and_resize(img[None], b, None, (7, 7))
+    assert np.array_equal(out[0, 0, 0], img[0, 0]) and np.array_equal(out[0, 6, 6], img[699, 799])
+    assert not out[1].any()
+    out2 = tf_image.crop_and_resize((2 * img)[None], b, None, (7, 7))
+    assert np.array_equal(out2, 2 * out)
+    sub = rng.choice(1024, 64, replace=False)
+    want = tfops.crop_and_resize(img, b[sub], 7, 7)
+    assert np.array_equal(out[sub], want)
+
+
+def test_crop_rejects_bad_input():
+    with pytest.raises(ValueError):
+        tf_image.crop_and_resize(np.zeros((2, 4, 4, 1), np.float32), np.zeros((1, 4)), None, (3, 3))
+    with pytest.raises(ValueError):
+        tf_image.crop_and_resize(np.zeros((1, 4, 4, 1), np.float32), np.zeros((1, 5)), None, (3, 3))
+
+
+def _nms_case(rng, n, scale):
+    cy, cx = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    h, w = rng.uniform(0.01, scale, n), rng.uniform(0.01, scale, n)
+    boxes = np.stack([cy - h, cx - w, cy + h, cx + w], 1).astype(np.float32)
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    return boxes, scores
+
+
+@pytest.mark.parametrize('n,k,thr,scale', [
+    (1, 10, 0.5, 0.1), (2, 1, 0.5, 0.1), (63, 100, 0.5, 0.2), (64, 64, 0.3, 0.2),
+    (65, 1000, 0.8, 0.2), (1000, 100, 0.01, 0.05), (2048, 300, 0.8, 0.1),
+    (2049, 1024, 0.8, 0.1), (4100, 1024, 0.5, 0.05), (8192, 1024, 0.8, 0.03),
+    (9000, 300, 0.8, 0.03), (14000, 1024, 0.8, 0.03), (20000, 2000, 0.6, 0.02)])
+def test_nms_matches_oracle(n, k, thr, scale):
+    rng = np.random.default_rng(n * 31 + k)
+    boxes, scores = _nms_case(rng, n, scale)
+    got = tf_image.non_max_suppression(boxes, scores, k, thr)
+    want = tfops.non_max_suppression_fast(boxes, scores, k, thr)
+    assert got.dtype == np.int32
+    assert np.array_equal(got, want)
+
+
+def test_nms_ties_zero_area_and_flipped_boxes():
+    rng = np.random.default_rng(17)
+    boxes, scores = _nms_case(rng, 3000, 0.08)
+    scores[100:400] = scores[100]                 # many exact ties -> index order
+    scores[1000:1100] = np.float32(-0.5)          # negative scores sort last
+    boxes[::41, 2] = boxes[::41, 0]               # zero area: never suppress / suppressed
+    boxes[5::53] = boxes[5::53][:, [2, 3, 0, 1]]  # corners given max-first
+    boxes[7] = boxes[6]                           # exact duplicate
+    for thr, k in ((0.8, 1024), (0.01, 100), (0.5, 3000)):
+        got = tf_image.non_max_suppression(boxes, scores, k, thr)
+        want = tfops.non_max_suppression_fast(boxes, scores, k, thr)
+        assert np.array_equal(got, want)
+
+
+def test_nms_properties_full_size():
+    """A = 14k anchors-like boxes: output is sorted by score, has no pair above
+    the threshold, and running NMS on its own output is the identity."""
+    rng = np.random.default_rng(23)
+    boxes, scores = _nms_case(rng, 14000, 0.04)
+    thr = np.float32(0.8)
+    sel = tf_image.non_max_suppression(boxes, scores, 1024, thr)
+    assert len(sel) == 1024 and len(set(sel.tolist())) == 1024
+    assert np.all(np.diff(scores[sel].astype(np.float64)) <= 0)
+    again = tf_image.non_max_suppression(boxes[sel], scores[sel], 1024, thr)
+    assert np.array_equal(again, np.arange(1024))
+
+
+def test_nms_rejects_bad_input():
+    with pytest.raises(ValueError):
+        tf_image.non_max_suppression(np.zeros((4, 3)), np.zeros(4), 2, 0.5)
+    with pytest.raises(ValueError):
+        tf_image.non_max_suppression(np.zeros((4, 4)), np.zeros(3), 2, 0.5)
+    with pytest.raises(ValueError):
+        tf_image.non_max_suppression(np.zeros((4, 4)), np.zeros(4), 2, 1.5)
+    assert len(tf_image.non_max_suppression(np.zeros((0, 4)), np.zeros(0), 5, 0.5)) == 0
+
+
+def test_encoders_match_golden_and_oracle(golden_dir):
+    enc = np.load(os.path.join(golden_dir, 'encoders.npz'))
+    anchors = enc['anchor_ortho'].astype(np.float32)
+    off = enc['anchor_offsets'].astype(np.float32)
+    got = gpu_anchor_encoder.offset_to_anchor(anchors, off)
+    np.testing.assert_allclose(got, enc['regressed_anchors'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got, oboxes.offset_to_anchor(anchors, off, np.float32),
+                               rtol=2e-6, atol=1e-6)
+    # stage-2 decode chain
+    rng = np.random.default_rng(5)
+    top = anchors.copy()
+    off4c = rng.normal(0, 0.15, size=(len(top), 10)).astype(np.float32)
+    plane = C['ground_plane']
+    b3, panc, bev = gpu_box_4c.decode_box_4c_predictions(top, off4c, plane, C['bev_extents'])
+    o_b3 = oboxes.anchors_to_box_3d(top, fix_lw=True, dtype=np.float32)
+    o_4c = oboxes.box_3d_to_box_4c(o_b3, plane, np.float32)
+    o_pred = oboxes.box_4c_to_box_3d(oboxes.offsets_to_box_4c(o_4c, off4c), plane, np.float32)
+    np.testing.assert_allclose(b3, o_pred, atol=1e-4)        # north_star: 1e-4 fp32
+    o_anc = oboxes.box_3d_to_anchor_ortho(o_pred, np.float32)
+    np.testing.assert_allclose(panc, o_anc, atol=1e-4)
+    o_bev, _ = oboxes.project_to_bev(o_anc, C['bev_extents'], np.float32)
+    np.testing.assert_allclose(bev, o_bev[:, [1, 0, 3, 2]], atol=1e-4)
+    # the numpy-branch golden (float64) of the same chain without offsets
+    b3z, _, _ = gpu_box_4c.decode_box_4c_predictions(
+        top, np.zeros_like(off4c), plane, C['bev_extents'])
+    want = oboxes.box_4c_to_box_3d(
+        oboxes.box_3d_to_box_4c(enc['box_3d_from_anchor'], plane, np.float64), plane, np.float64)
+    np.testing.assert_allclose(b3z[:, :6], want[:, :6], atol=1e-4)
+
+
+def test_softmax_and_gather(ctx):
+    rng = np.random.default_rng(9)
+    logits = rng.normal(0, 3, size=(5000, 2)).astype(np.float32)
+    d_out = ctx.empty((5000,), np.float32)
+    ops.softmax_fg(ctx, ctx.array(logits), 5000, None, d_out)
+    np.testing.assert_allclose(d_out.download(), tfops.softmax2(logits)[:, 1],
+                               rtol=2e-6, atol=1e-7)
+    src = rng.normal(size=(700, 6)).astype(np.float32)
+    idx = rng.integers(0, 700, 300).astype(np.int32)
+    d_g = ctx.empty((300, 6), np.float32)
+    ops.gather_rows(ctx, ctx.array(src), 6, ctx.array(idx), 300, None, d_g)
+    assert np.array_equal(d_g.download(), src[idx])
