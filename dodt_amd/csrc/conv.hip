@@ -265,6 +265,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     setb(C4A, H / 8, W / 8, 256); setb(C4B, H / 8, W / 8, 256); setb(C4C, H / 8, W / 8, 256);
     setb(F3, H / 4, W / 4, 64); setb(F2, H / 2, W / 2, 32); setb(F1, H, W, 32);
     for (int i = 0; i < NBUF; ++i) {
+        if (i == F1) continue;  // the last layer writes into the caller's buffer
         const size_t bytes = ex->buf[i].frame_floats() * batch * sizeof(float);
         hipError_t e = hipMalloc(&ex->buf[i].ptr, bytes);
         if (e != hipSuccess) {
@@ -458,6 +459,8 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
     DODT_REQUIRE(li >= 0, "dodt_extractor_read_activation: unknown layer '%s'", name);
     const Layer& l = ex->layers[li];
     const Buffer& b = ex->buf[buffer_for_layer_output(l)];
+    DODT_REQUIRE(b.ptr != nullptr,
+                 "layer %s is written straight into the caller's output buffer", name);
     const int oh = l.deconv ? 2 * l.H : l.H, ow = l.deconv ? 2 * l.W : l.W;
     if (h) *h = oh;
     if (w) *w = ow;

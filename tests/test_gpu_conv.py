@@ -29,7 +29,7 @@ def _check_all_layers(ex, params, x, pad_top):
         oext.vgg_pyramid(x[f], params, pad_top=pad_top, collect=c)
         for k, v in c.items():
             collect.setdefault(k, []).append(v)
-    for name in synth.PYRAMID_LAYERS:
+    for name in synth.PYRAMID_LAYERS[:-1]:     # the last layer is the returned map
         _close(ex.activation(name), np.stack(collect[name]), name)
 
 
