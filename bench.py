@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/sec of the DODT hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+One step = one pass of the hot path over one synthetic KITTI-shaped frame pair
+(2 x 120k points + 2 x 1242x375 RGB, tau = 2) whose inputs are already resident
+in HBM.  Frame pairs shard across ranks (pair i -> rank i mod N, weak scaling);
+after each step the ranks all-gather their detection records (RCCL).  Rank 0
+prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--points', type=int, default=120000)
+    ap.add_argument('--proposals', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, synth, budget_s):
+    """The oracle ('port' of the reference's algorithm) timed on this host: whole
+    frame pairs -- numpy point path + numpy conv stacks + crop/NMS -- until about
+    budget_s seconds have been spent.  Test infrastructure used as a yardstick,
+    never as the product."""
+    from oracle import pipeline as opipe
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    bev_params = synth.pyramid_params(6, 42)
+    img_params = synth.pyramid_params(3, 142)
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        f = frames
+        xyzi = synth.lidar_frame(9, f)
+        img = synth.image_frame(9, f)
+        heads = synth.head_outputs(9, f, 89600, 1024)
+        inp = opipe.frame_inputs(xyzi, cfg, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                 synth.IMAGE_WH)
+        feats = opipe.extract(inp['bev'], img, bev_params, img_params, cfg['img_dims'])
+        opipe.frame_detections(inp, heads, cfg, synth.P2, synth.IMAGE_WH, 1024, *feats)
+        frames += 1
+        el = time.perf_counter() - t0
+        if frames >= 2 and (el > budget_s or frames >= 8):
+            break
+    return dict(value=(frames / 2.0) / el, unit='frame-pairs/s', cores=int(cores), kind='port',
+                sample='%d synthetic frames (%.1f pairs) through oracle/pipeline.py: numpy '
+                       'point path + numpy/BLAS fp32 conv stacks + crop + NMS' %
+                       (frames, frames / 2.0))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    n_gpus = max(args.gpus, 1)
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from dodt_amd import config, device, synth
+    from dodt_amd.pipeline import FramePairPipeline, MAX_DET, REC_COLS
+    cfg = config.PYRAMID_DODT
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = device.Context(local_rank, stream=stream)
+    pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals)
+
+    # detection records live in torch memory so that RCCL can ship them
+    rec = torch.zeros((2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
+    cnt = torch.zeros((2,), dtype=torch.int32, device='cuda')
+    pipe.use_record_buffers(rec.data_ptr(), cnt.data_ptr())
+    gathered = torch.zeros((world, 2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
+    gathered_cnt = torch.zeros((world, 2), dtype=torch.int32, device='cuda')
+
+    # a small ring of distinct synthetic pairs, resident in HBM before timing starts
+    n_pairs = 4
+    pairs = []
+    for i in range(n_pairs):
+        seq = rank * n_pairs + i
+        frames = (2 * i, 2 * i + 2)                                  # tau = 2
+        pts = [synth.lidar_frame(seq, f, args.points) for f in frames]
+        pairs.append(dict(
+            pts=[ctx.array(p) for p in pts], n=[len(p) for p in pts],
+            imgs=[ctx.array(synth.image_frame(seq, f)) for f in frames],
+            heads=[{k: ctx.array(v) for k, v in
+                    synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()} for f in frames]))
+
+    def step(i):
+        p = pairs[i % n_pairs]
+        pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, rec)
+            dist.all_gather_into_tensor(gathered_cnt, cnt)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel family: the conv stacks -----------------------
+    # measured live with HIP events on the stream the kernels run on
+    reps = max(3, min(args.steps, 10))
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        pipe.bev_net.forward_device(None, pipe.d_bev_feat, pipe.d_bev_bneck)
+        pipe.img_net.forward_device(None, pipe.d_img_feat, pipe.d_img_bneck)
+    conv_ms = ctx.timer_stop() / reps
+    flops = pipe.flops_per_pair()
+    achieved = flops / (conv_ms * 1e-3) / 1e12
+    peak = 157.3      # TFLOP/s, fp32 MFMA, MI355X_MICROARCH.md chip table
+    roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
+                    frac=round(achieved / peak, 4), traffic=None,
+                    kernel='conv3x3_mfma_kernel (32 conv launches per pair)',
+                    launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2))
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            'metric': 'frame-pairs/sec (whole node) KITTI-shape tau=2',
+            'value': round(world * args.steps / elapsed, 3),
+            'unit': 'frame-pairs/s', 'n_gpus': n_gpus, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
+                                   'pyramid_cars_with_aug_dt_5_tracking, %d proposals, '
+                                   'S path (heads injected)' % (args.points // 1000,
+                                                                args.proposals),
+                       'pairs_per_step_per_gpu': 1, 'parallelism': 'pair-shard x%d' % world,
+                       'anchors_kept': pipe.last_anchor_counts},
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(cfg, synth, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -58,6 +58,8 @@ SIGNATURES = {
     'dodt_memcpy_h2d': (_i, [_vp, _vp, _vp, C.c_size_t]),
     'dodt_memcpy_d2h': (_i, [_vp, _vp, _vp, C.c_size_t]),
     'dodt_memset': (_i, [_vp, _vp, _i, C.c_size_t]),
+    'dodt_fetch_i32_begin': (_i, [_vp, _pi32, _i, _i]),
+    'dodt_fetch_i32_end': (_i, [_vp, _i, C.POINTER(C.c_int32), _i]),
     'dodt_timer_start': (_i, [_vp]),
     'dodt_timer_stop': (_i, [_vp, C.POINTER(_f)]),
     'dodt_bev_slices': (_i, [_vp, _vp, _i, C.POINTER(BevParams), _pf, _vp]),
@@ -87,6 +89,8 @@ SIGNATURES = {
     'dodt_offset_to_anchor': (_i, [_vp, _pf, _pf, _i, _pi32, _pf]),
     'dodt_softmax_fg': (_i, [_vp, _pf, _i, _pi32, _pf]),
     'dodt_gather_rows': (_i, [_vp, _pf, _i, _pi32, _i, _pi32, _pf]),
+    'dodt_max_fg_logit': (_i, [_vp, _pf, _i, _i, _pi32, _pf]),
+    'dodt_pack_detections': (_i, [_vp, _pf, _pf, _pi32, _pi32, _i, _f, _pf, _pi32]),
     'dodt_box_4c_decode': (_i, [_vp, _pf, _pf, _i, _pi32, C.POINTER(_f),
                                 C.POINTER(_f), _pf, _pf, _pf]),
 }

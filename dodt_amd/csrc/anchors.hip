@@ -245,6 +245,36 @@ gather_rows_kernel(const float* __restrict__ src, int width, const int* __restri
     out[(size_t)i * width + c] = src[(size_t)idx[i] * width + c];
 }
 
+__global__ void __launch_bounds__(256)
+max_fg_logit_kernel(const float* __restrict__ logits, int n_cls, int n,
+                    const int* __restrict__ d_n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = d_n ? min(*d_n, n) : n;
+    if (i >= lim) return;
+    float m = logits[(size_t)i * n_cls + 1];
+    for (int c = 2; c < n_cls; ++c) m = fmaxf(m, logits[(size_t)i * n_cls + c]);
+    out[i] = m;
+}
+
+__global__ void __launch_bounds__(256)
+pack_detections_kernel(const float* __restrict__ boxes_3d, const float* __restrict__ scores,
+                       const int* __restrict__ sel, const int* __restrict__ d_count, int max_det,
+                       float frame_mark, float* __restrict__ rec, int* __restrict__ count_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cnt = min(*d_count, max_det);
+    if (t == 0) *count_out = cnt;
+    if (t >= max_det * 17) return;
+    const int row = t / 17, col = t - row * 17;
+    float v = 0.0f;
+    if (row < cnt) {
+        const int src = sel[row];
+        if (col < 7) v = boxes_3d[(size_t)src * 7 + col];
+        else if (col == 7) v = scores[src];
+        else if (col == 16) v = frame_mark;
+    }
+    rec[t] = v;
+}
+
 // calculate_box_3d_info (box_4c_encoder.py:305-366) for one candidate midline
 __device__ __forceinline__ void box_info32(float vx, float vz, float mag, const float* px,
                                            const float* pz, float mx, float mz, float& cx,
@@ -440,6 +470,29 @@ int dodt_gather_rows(dodt_ctx* ctx, const float* d_src, int width, const int32_t
     if (n <= 0) return DODT_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(dodt::ceil_div(n * width, 256)), dim3(256), 0,
                        ctx->stream, d_src, width, d_idx, n, d_n, d_out);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int dodt_max_fg_logit(dodt_ctx* ctx, const float* d_logits, int n_cls, int n, const int32_t* d_n,
+                      float* d_scores_out) {
+    DODT_REQUIRE(ctx && d_logits && d_scores_out && n_cls >= 2, "dodt_max_fg_logit: bad argument");
+    if (n <= 0) return DODT_OK;
+    hipLaunchKernelGGL(max_fg_logit_kernel, dim3(dodt::ceil_div(n, 256)), dim3(256), 0,
+                       ctx->stream, d_logits, n_cls, n, d_n, d_scores_out);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int dodt_pack_detections(dodt_ctx* ctx, const float* d_boxes_3d, const float* d_scores,
+                         const int32_t* d_sel, const int32_t* d_count, int max_det,
+                         float frame_mark, float* d_rec_out, int32_t* d_count_out) {
+    DODT_REQUIRE(ctx && d_boxes_3d && d_scores && d_sel && d_count && d_rec_out && d_count_out &&
+                     max_det > 0,
+                 "dodt_pack_detections: bad argument");
+    hipLaunchKernelGGL(pack_detections_kernel, dim3(dodt::ceil_div(max_det * 17, 256)), dim3(256),
+                       0, ctx->stream, d_boxes_3d, d_scores, d_sel, d_count, max_det, frame_mark,
+                       d_rec_out, d_count_out);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
 }

@@ -55,4 +55,6 @@ struct dodt_ctx {
     dodt::Scratch anchor_ws; // anchor filter: mask + block counts
     dodt::Scratch nms_ws;    // NMS: keys, sorted boxes, suppression mask
     int num_cus = 256;
+    int32_t* pinned = nullptr;       // 8 slots x 16 int32, hipHostMalloc
+    hipEvent_t fetch_ev[8] = {};
 };

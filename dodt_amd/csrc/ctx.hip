@@ -67,6 +67,8 @@ static int ctx_create(int device_id, hipStream_t stream, bool external, dodt_ctx
     }
     (void)hipEventCreate(&c->ev_start);
     (void)hipEventCreate(&c->ev_stop);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 8 * 16 * sizeof(int32_t), 0);
+    for (int i = 0; i < 8; ++i) (void)hipEventCreateWithFlags(&c->fetch_ev[i], hipEventDisableTiming);
     *out = c;
     return DODT_OK;
 }
@@ -86,6 +88,9 @@ int dodt_ctx_destroy(dodt_ctx* ctx) {
     ctx->vox_ws.release();
     ctx->anchor_ws.release();
     ctx->nms_ws.release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->fetch_ev[i]) (void)hipEventDestroy(ctx->fetch_ev[i]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -133,6 +138,23 @@ int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes) {
     DODT_REQUIRE(ctx && (bytes == 0 || d_dst), "dodt_memset: NULL argument");
     if (bytes == 0) return DODT_OK;
     DODT_HIP_CHECK(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_fetch_i32_begin(dodt_ctx* ctx, const int32_t* d_src, int n, int slot) {
+    DODT_REQUIRE(ctx && d_src && ctx->pinned, "dodt_fetch_i32_begin: NULL argument");
+    DODT_REQUIRE(n >= 1 && n <= 16 && slot >= 0 && slot < 8, "dodt_fetch_i32_begin: bad n/slot");
+    DODT_HIP_CHECK(hipMemcpyAsync(ctx->pinned + slot * 16, d_src, n * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    DODT_HIP_CHECK(hipEventRecord(ctx->fetch_ev[slot], ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_fetch_i32_end(dodt_ctx* ctx, int slot, int32_t* dst, int n) {
+    DODT_REQUIRE(ctx && dst && ctx->pinned, "dodt_fetch_i32_end: NULL argument");
+    DODT_REQUIRE(n >= 1 && n <= 16 && slot >= 0 && slot < 8, "dodt_fetch_i32_end: bad n/slot");
+    DODT_HIP_CHECK(hipEventSynchronize(ctx->fetch_ev[slot]));
+    for (int i = 0; i < n; ++i) dst[i] = ctx->pinned[slot * 16 + i];
     return DODT_OK;
 }
 

@@ -123,3 +123,28 @@ def box_4c_decode(ctx, d_top_anchors, d_offsets, n, d_n, plane, bev_extents,
         ctx.handle, _p(d_top_anchors), _p(d_offsets), int(n), _p(d_n),
         _arr(C.c_float, plane), _arr(C.c_float, bev_extents), _p(d_boxes_3d),
         _p(d_pred_anchors), _p(d_bev_tf)), 'dodt_box_4c_decode')
+
+
+def max_fg_logit(ctx, d_logits, n_cls, n, d_n, d_scores):
+    _lib.check(ctx.lib.dodt_max_fg_logit(
+        ctx.handle, _p(d_logits), int(n_cls), int(n), _p(d_n), _p(d_scores)),
+        'dodt_max_fg_logit')
+
+
+def pack_detections(ctx, d_boxes_3d, d_scores, d_sel, d_count, max_det, frame_mark,
+                    d_rec, d_count_out):
+    _lib.check(ctx.lib.dodt_pack_detections(
+        ctx.handle, _p(d_boxes_3d), _p(d_scores), _p(d_sel), _p(d_count), int(max_det),
+        float(frame_mark), _p(d_rec), _p(d_count_out)), 'dodt_pack_detections')
+
+
+def fetch_i32_begin(ctx, d_src, n, slot):
+    _lib.check(ctx.lib.dodt_fetch_i32_begin(ctx.handle, _p(d_src), int(n), int(slot)),
+               'dodt_fetch_i32_begin')
+
+
+def fetch_i32_end(ctx, slot, n):
+    buf = (C.c_int32 * n)()
+    _lib.check(ctx.lib.dodt_fetch_i32_end(ctx.handle, int(slot), buf, int(n)),
+               'dodt_fetch_i32_end')
+    return list(buf)

@@ -1,1 +1,172 @@
-"""Frame-pair pipeline (filled in below)."""
+"""Frame-pair pipeline: the per-frame hot path of DODT chained on one GPU.
+
+Order of work follows the reference's inference call stack:
+create_feed_dict (points -> BEV maps, anchor grid -> empty filter -> projections;
+avod/core/models/dt_rpn_model.py:732-1042) then the graph
+(dt_rpn_model.py:355-730, dt_avod_model.py:128-711).  The dense heads between
+crop and NMS (anchor predictor, stage-2 FC) are "next" rows of SURVEY 8(f): their
+outputs are inputs of this pipeline (`heads`), resident in HBM.
+
+Everything stays on the device; the only host round trip per pair is the pair of
+kept-anchor counts, fetched while the conv stacks run.
+"""
+import numpy as np
+
+from dodt_amd import _lib, ops, synth
+from dodt_amd.core.anchor_generators import grid_anchor_3d_generator as gen
+from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr, ImgVggPyr
+
+MAX_DET = 100            # avod_nms_size
+REC_COLS = 17            # dt_evaluator.py:1217-1257
+
+
+class FramePairPipeline(object):
+    def __init__(self, ctx, cfg, p2=synth.P2, r0_rect=synth.R0_RECT,
+                 tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
+                 n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None):
+        self.ctx = ctx
+        self.cfg = cfg
+        self.p2 = np.asarray(p2, dtype=np.float64)
+        self.image_wh = tuple(image_wh)
+        self.P = int(rpn_nms_size)
+        self.bev_h, self.bev_w = cfg['bev_dims']
+        self.img_h, self.img_w = cfg['img_dims']
+        self.n_slices = cfg['num_slices']
+        self.bev_extents_flat = np.asarray(cfg['bev_extents'], np.float64).reshape(-1)
+        self.bp = ops.make_bev_params(cfg, synth.velo_to_cam(r0_rect, tr_velo_to_cam),
+                                      self.p2, self.image_wh)
+
+        # ---- constants of the configuration, resident on the device ----------------
+        boxes = gen.tile_anchors_3d(cfg['area_extents'], cfg['anchor_sizes'],
+                                    cfg['anchor_stride'], cfg['ground_plane'])
+        self.anchors_all = gen.box_3d_to_anchor(boxes)            # (N,6) float64
+        cells, self.nx, self.nz = gen.anchor_grid_cells(
+            self.anchors_all, cfg['area_extents'], cfg['voxel_size'])
+        self.n_all = len(self.anchors_all)
+        self.d_anchor_table = ctx.array(self.anchors_all)
+        self.d_cells = ctx.array(cells)
+
+        # ---- extractors (both frames of the pair are one batch) ----------------------
+        self.bev_net = BevVggPyr(ctx=ctx)
+        self.bev_net.load_params(bev_params or synth.pyramid_params(cfg['bev_depth'], 42))
+        self.bev_net._ensure(2, self.bev_h, self.bev_w, cfg['bev_depth'])
+        self.img_net = ImgVggPyr(ctx=ctx)
+        self.img_net.load_params(img_params or synth.pyramid_params(cfg['img_depth'], 142))
+        self.img_net._ensure(2, self.img_h, self.img_w, 4)
+        p, s = self.bev_net.input_view()
+        self.d_bev_in = [ctx.wrap(p + 4 * s * f, (self.bev_h, self.bev_w, cfg['bev_depth']))
+                         for f in range(2)]
+        p, s = self.img_net.input_view()
+        self.d_img_in = [ctx.wrap(p + 4 * s * f, (self.img_h, self.img_w, 4)) for f in range(2)]
+
+        # ---- per-pair work buffers -----------------------------------------------------
+        f32, i32 = np.float32, np.int32
+        N, P = self.n_all, self.P
+        self.d_bev_feat = ctx.empty((2, self.bev_h, self.bev_w, 32), f32)
+        self.d_bev_bneck = ctx.empty((2, self.bev_h, self.bev_w, 1), f32)
+        self.d_img_feat = ctx.empty((2, self.img_h, self.img_w, 32), f32)
+        self.d_img_bneck = ctx.empty((2, self.img_h, self.img_w, 1), f32)
+        self.fr = []
+        for f in range(2):
+            b = dict(
+                occ=ctx.empty((self.nz, (self.nx + 31) // 32), np.uint32),
+                keep=ctx.empty((N,), i32), count=ctx.zeros((1,), i32),
+                bev_norm=ctx.empty((N, 4), f32), img_norm=ctx.empty((N, 4), f32),
+                anchors=ctx.empty((N, 6), f32),
+                rpn_bev_roi=ctx.empty((N, 3, 3, 1), f32), rpn_img_roi=ctx.empty((N, 3, 3, 1), f32),
+                regressed=ctx.empty((N, 6), f32), prop_bev=ctx.empty((N, 4), f32),
+                scores=ctx.empty((N,), f32),
+                top_idx=ctx.empty((P,), i32), top_count=ctx.zeros((1,), i32),
+                top_anchors=ctx.empty((P, 6), f32),
+                top_bev=ctx.empty((P, 4), f32), top_img=ctx.empty((P, 4), f32),
+                bev_rois=ctx.empty((P, 7, 7, 32), f32), img_rois=ctx.empty((P, 7, 7, 32), f32),
+                boxes_3d=ctx.empty((P, 7), f32), pred_anchors=ctx.empty((P, 6), f32),
+                nms2_boxes=ctx.empty((P, 4), f32), nms2_scores=ctx.empty((P,), f32),
+                det_idx=ctx.empty((MAX_DET,), i32), det_count=ctx.zeros((1,), i32))
+            self.fr.append(b)
+        # detection records of the pair: what the all-gather ships
+        self.d_records = ctx.empty((2, MAX_DET, REC_COLS), f32)
+        self.d_rec_counts = ctx.zeros((2,), i32)
+        self.last_anchor_counts = [0, 0]
+
+    def use_record_buffers(self, rec_ptr, cnt_ptr):
+        """Write detection records into caller-owned device memory (e.g. the
+        torch tensor handed to torch.distributed.all_gather)."""
+        self.d_records = self.ctx.wrap(rec_ptr, (2, MAX_DET, REC_COLS), np.float32)
+        self.d_rec_counts = self.ctx.wrap(cnt_ptr, (2,), np.int32)
+
+    # ------------------------------------------------------------------------------------
+    def run(self, d_points, n_points, d_images, heads):
+        """d_points[f]: (n,4) float32 velodyne xyzi; d_images[f]: (H,W,3) uint8;
+        heads[f]: dict of device arrays rpn_logits (N,2), rpn_offsets (N,6),
+        cls_logits (P,2), offsets_4c (P,10).  All asynchronous on ctx's stream."""
+        ctx, cfg = self.ctx, self.cfg
+        mean = (ImgVggPyr._R_MEAN, ImgVggPyr._G_MEAN, ImgVggPyr._B_MEAN)
+        # -- a0-a7: data side of the reference's create_feed_dict ------------------------
+        for f in range(2):
+            b = self.fr[f]
+            ops.bev_slices(ctx, d_points[f], n_points[f], self.bp, self.d_bev_in[f], b['occ'])
+            ops.anchor_filter(ctx, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
+                              b['keep'], b['count'])
+            ops.fetch_i32_begin(ctx, b['count'], 1, f)
+            ops.project_anchors_f64(ctx, self.d_anchor_table, b['keep'], self.n_all, b['count'],
+                                    self.bev_extents_flat, self.p2, self.image_wh,
+                                    b['bev_norm'], b['img_norm'], b['anchors'])
+            ops.img_preprocess(ctx, d_images[f], (self.image_wh[1], self.image_wh[0]),
+                               (self.img_h, self.img_w), 4, mean, self.d_img_in[f])
+        # -- a8-a10: conv stacks, both frames per launch ----------------------------------
+        self.bev_net.forward_device(None, self.d_bev_feat, self.d_bev_bneck)
+        self.img_net.forward_device(None, self.d_img_feat, self.d_img_bneck)
+        # kept-anchor counts arrived long ago; the convs are still running
+        counts = [ops.fetch_i32_end(ctx, f, 1)[0] for f in range(2)]
+        self.last_anchor_counts = counts
+        bev_px = self.bev_h * self.bev_w
+        img_px = self.img_h * self.img_w
+        plane = cfg['ground_plane']
+        for f in range(2):
+            b, h, A = self.fr[f], heads[f], counts[f]
+            bneck_b = self.d_bev_bneck.offset(4 * bev_px * f, (self.bev_h, self.bev_w, 1))
+            bneck_i = self.d_img_bneck.offset(4 * img_px * f, (self.img_h, self.img_w, 1))
+            feat_b = self.d_bev_feat.offset(4 * bev_px * 32 * f, (self.bev_h, self.bev_w, 32))
+            feat_i = self.d_img_feat.offset(4 * img_px * 32 * f, (self.img_h, self.img_w, 32))
+            # -- a11: RPN crops (3x3 on the 1-channel bottlenecks) ------------------------
+            ops.crop_and_resize(ctx, bneck_b, (self.bev_h, self.bev_w, 1), b['bev_norm'], A, None,
+                                (3, 3), b['rpn_bev_roi'])
+            ops.crop_and_resize(ctx, bneck_i, (self.img_h, self.img_w, 1), b['img_norm'], A, None,
+                                (3, 3), b['rpn_img_roi'])
+            # -- a12, a5, a13: decode, project, NMS #1 --------------------------------------
+            ops.offset_to_anchor(ctx, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
+            ops.project_anchors_f32(ctx, b['regressed'], A, None, self.bev_extents_flat, self.p2,
+                                    self.image_wh, d_bev_norm_tf=b['prop_bev'])
+            ops.softmax_fg(ctx, h['rpn_logits'], A, None, b['scores'])
+            ops.nms(ctx, b['prop_bev'], b['scores'], A, None, self.P,
+                    cfg['rpn_nms_iou_thresh'], b['top_idx'], b['top_count'])
+            ops.gather_rows(ctx, b['regressed'], 6, b['top_idx'], self.P, b['top_count'],
+                            b['top_anchors'])
+            # -- stage 2: project proposals, 7x7 crops --------------------------------------
+            ops.project_anchors_f32(ctx, b['top_anchors'], self.P, b['top_count'],
+                                    self.bev_extents_flat, self.p2, self.image_wh,
+                                    d_bev_norm_tf=b['top_bev'], d_img_norm_tf=b['top_img'])
+            ops.crop_and_resize(ctx, feat_b, (self.bev_h, self.bev_w, 32), b['top_bev'], self.P,
+                                b['top_count'], (7, 7), b['bev_rois'])
+            ops.crop_and_resize(ctx, feat_i, (self.img_h, self.img_w, 32), b['top_img'], self.P,
+                                b['top_count'], (7, 7), b['img_rois'])
+            # -- a14, a13: box_4c decode, NMS #2 ---------------------------------------------
+            ops.box_4c_decode(ctx, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
+                              plane, self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'],
+                              b['nms2_boxes'])
+            ops.max_fg_logit(ctx, h['cls_logits'], 2, self.P, b['top_count'], b['nms2_scores'])
+            ops.nms(ctx, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
+                    cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
+            ops.pack_detections(
+                ctx, b['boxes_3d'], b['nms2_scores'], b['det_idx'], b['det_count'], MAX_DET,
+                float(f), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
+                self.d_rec_counts.offset(4 * f, (1,), np.int32))
+        return counts
+
+    def flops_per_pair(self):
+        return self.bev_net.flops() + self.img_net.flops()
+
+    def close(self):
+        self.bev_net.close()
+        self.img_net.close()

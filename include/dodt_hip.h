@@ -55,6 +55,13 @@ int dodt_memcpy_h2d(dodt_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int dodt_memcpy_d2h(dodt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes);
 
+/* Small device->host reads that do not stall the stream: begin enqueues a copy of
+ * n <= 16 int32 into pinned slot `slot` (0..7) and records an event; end waits for
+ * that event only (kernels enqueued after begin keep running) and returns the
+ * values.  Used to learn the kept-anchor count while the conv stacks run. */
+int dodt_fetch_i32_begin(dodt_ctx* ctx, const int32_t* d_src, int n, int slot);
+int dodt_fetch_i32_end(dodt_ctx* ctx, int slot, int32_t* dst, int n);
+
 /* HIP-event stopwatch on the ctx stream: start; ...launches...; stop -> ms
  * (stop waits for the stream). */
 int dodt_timer_start(dodt_ctx* ctx);
@@ -208,6 +215,18 @@ int dodt_softmax_fg(dodt_ctx* ctx, const float* d_logits2, int n, const int32_t*
  * dt_rpn_model.py:593-597, dt_avod_model.py:616-640) */
 int dodt_gather_rows(dodt_ctx* ctx, const float* d_src, int width, const int32_t* d_idx,
                      int n, const int32_t* d_n, float* d_out);
+/* NMS #2 score: max over the non-background logits, column 1.. of (n,n_cls)
+ * (models/dt_avod_model.py:606: tf.reduce_max(all_cls_logits[:, 1:], axis=1)) */
+int dodt_max_fg_logit(dodt_ctx* ctx, const float* d_logits, int n_cls, int n,
+                      const int32_t* d_n, float* d_scores_out);
+/* Detection record of one frame, the 17 columns the evaluator writes per box
+ * (avod/core/dt_evaluator.py:1217-1257): box_3d(7), score, class index,
+ * 7 zeros (the corr-shifted box: T branch, not on this path), frame mark.
+ * Rows d_sel[0..*d_count) of boxes_3d / scores; remaining rows of the
+ * (max_det,17) output are zeroed; d_count_out[0] = *d_count. */
+int dodt_pack_detections(dodt_ctx* ctx, const float* d_boxes_3d, const float* d_scores,
+                         const int32_t* d_sel, const int32_t* d_count, int max_det,
+                         float frame_mark, float* d_rec_out, int32_t* d_count_out);
 /* Stage-2 decode (models/dt_avod_model.py:464-469,575-603):
  *   anchors_to_box_3d(fix_lw) -> tf_box_3d_to_box_4c -> + offsets ->
  *   tf_box_4c_to_box_3d -> tf_box_3d_to_anchor -> project_to_bev (metres) ->

@@ -1,0 +1,84 @@
+"""End-to-end frame pair on the GPU against the oracle: anchor indices and NMS keep
+lists bit-exact, regressed boxes within 1e-4 (the north_star's parity bar)."""
+import numpy as np
+import pytest
+
+from dodt_amd import config, device, synth
+from dodt_amd.pipeline import FramePairPipeline, MAX_DET
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+C = config.PYRAMID_DODT
+
+
+@pytest.fixture(scope='module')
+def setup():
+    ctx = device.default_context()
+    pipe = FramePairPipeline(ctx, C, rpn_nms_size=1024)
+    return ctx, pipe
+
+
+def _run(ctx, pipe, seq, frames, n_points=120000):
+    pts = [synth.lidar_frame(seq, f, n_points) for f in frames]
+    imgs = [synth.image_frame(seq, f) for f in frames]
+    heads = [synth.head_outputs(seq, f, pipe.n_all, pipe.P) for f in frames]
+    d_pts = [ctx.array(p) for p in pts]
+    d_imgs = [ctx.array(i) for i in imgs]
+    d_heads = [{k: ctx.array(v) for k, v in h.items()} for h in heads]
+    counts = pipe.run(d_pts, [len(p) for p in pts], d_imgs, d_heads)
+    ctx.sync()
+    return pts, imgs, heads, counts
+
+
+def test_frame_pair_matches_oracle(setup):
+    ctx, pipe = setup
+    pts, imgs, heads, counts = _run(ctx, pipe, seq=0, frames=(0, 2))    # tau = 2
+    recs = pipe.d_records.download()
+    rcnt = pipe.d_rec_counts.download()
+    bev_params = synth.pyramid_params(6, 42)
+    img_params = synth.pyramid_params(3, 142)
+    for f in range(2):
+        b = pipe.fr[f]
+        inp = opipe.frame_inputs(pts[f], C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                 synth.IMAGE_WH)
+        A = len(inp['keep'])
+        assert counts[f] == A and A > 1000
+        assert np.array_equal(b['keep'].download()[:A], inp['keep'])
+        assert np.array_equal(b['anchors'].download()[:A], inp['anchors'])
+        assert np.array_equal(b['bev_norm'].download()[:A], inp['bev_norm_tf'])
+        assert np.array_equal(b['img_norm'].download()[:A], inp['img_norm_tf'])
+        bev_in = pipe.d_bev_in[f].download()
+        assert np.array_equal(bev_in, inp['bev'])
+        feats = opipe.extract(inp['bev'], imgs[f], bev_params, img_params, C['img_dims']) \
+            if f == 0 else (None, None, None, None)
+        want = opipe.frame_detections(inp, heads[f], C, synth.P2, synth.IMAGE_WH, pipe.P, *feats)
+        # --- integer results: exact -------------------------------------------------------
+        n_top = int(b['top_count'].download()[0])
+        assert n_top == len(want['top_idx'])
+        assert np.array_equal(b['top_idx'].download()[:n_top], want['top_idx'])
+        n_det = int(b['det_count'].download()[0])
+        assert n_det == len(want['det_idx']) == rcnt[f]
+        assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
+        # --- float results: 1e-4 ---------------------------------------------------------------
+        np.testing.assert_allclose(b['regressed'].download()[:A], want['regressed'],
+                                   rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(b['boxes_3d'].download()[:n_top], want['boxes_3d'], atol=1e-4)
+        np.testing.assert_allclose(recs[f], want['records'] +
+                                   np.where(np.arange(MAX_DET)[:, None] < n_det,
+                                            np.eye(17, dtype=np.float32)[16] * f, 0), atol=1e-4)
+        if f == 0:
+            for name in ('rpn_bev_roi', 'rpn_img_roi', 'bev_rois', 'img_rois'):
+                got = b[name].download()[:len(want[name])]
+                scale = np.abs(want[name]).max() + 1e-12
+                assert np.abs(got - want[name]).max() <= 1e-4 * scale, name
+
+
+def test_pair_is_repeatable_and_independent(setup):
+    """Running another pair in between does not change the result (no state leaks
+    between pairs: frame-pairs shard freely across GPUs)."""
+    ctx, pipe = setup
+    _run(ctx, pipe, seq=1, frames=(4, 6))
+    r1 = pipe.d_records.download().copy()
+    _run(ctx, pipe, seq=2, frames=(1, 3))
+    _run(ctx, pipe, seq=1, frames=(4, 6))
+    assert np.array_equal(r1, pipe.d_records.download())
