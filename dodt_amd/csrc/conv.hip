@@ -27,48 +27,67 @@ using dodt::ConvArgs;
 // ---------------------------------------------------------------------------
 struct KernelVariant {
     int TW, MTB, WM, WN, BN, CK;
-    bool deconv;
+    bool deconv, small_cin;
     int TH, lds_bytes;
     void (*launch)(const ConvArgs&, dim3 grid, hipStream_t s);
     hipError_t (*prepare)();
 };
 
-template <int TW, int MTB, int WM, int WN, int BN, int CK, bool DECONV>
+template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
 struct Inst {
-    using Cfg = dodt::ConvCfg<TW, MTB, WM, WN, BN, CK, DECONV>;
+    using Cfg = dodt::ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
     static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL((dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, CK, DECONV>), grid,
+        hipLaunchKernelGGL((dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV>), grid,
                            dim3(256), Cfg::kLdsBytes, s, a);
     }
     static hipError_t prepare() {
         return hipFuncSetAttribute(
-            reinterpret_cast<const void*>(
-                &dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, CK, DECONV>),
+            reinterpret_cast<const void*>(&dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV>),
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
     }
     static KernelVariant variant() {
-        return KernelVariant{TW, MTB, WM, WN, BN, CK, DECONV, Cfg::TH, Cfg::kLdsBytes, &launch,
-                             &prepare};
+        return KernelVariant{TW, MTB, WM, WN, BN, dodt::kCK, DECONV, false, Cfg::TH,
+                             Cfg::kLdsBytes, &launch, &prepare};
+    }
+};
+
+template <int TW, int MTB, int CK>
+struct InstSmall {
+    using Cfg = dodt::SmallCfg<TW, MTB, CK>;
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL((dodt::conv3x3_small_cin_kernel<TW, MTB, CK>), grid, dim3(256),
+                           Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&dodt::conv3x3_small_cin_kernel<TW, MTB, CK>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        return KernelVariant{TW, MTB, 4, 1, 32, CK, false, true, Cfg::TH, Cfg::kLdsBytes,
+                             &launch, &prepare};
     }
 };
 
 const std::vector<KernelVariant>& variants() {
     static const std::vector<KernelVariant> v = {
-        Inst<32, 16, 4, 1, 32, 6, false>::variant(),
-        Inst<32, 16, 4, 1, 32, 16, false>::variant(),
-        Inst<16, 16, 4, 1, 32, 16, false>::variant(),
-        Inst<16, 16, 4, 1, 64, 16, false>::variant(),
-        Inst<16, 12, 4, 1, 32, 4, false>::variant(),
-        Inst<16, 12, 4, 1, 32, 16, false>::variant(),
-        Inst<8, 8, 4, 1, 32, 16, false>::variant(),
-        Inst<8, 8, 4, 1, 64, 16, false>::variant(),
-        Inst<8, 4, 2, 2, 128, 8, false>::variant(),
-        Inst<8, 4, 4, 1, 64, 16, false>::variant(),
-        Inst<4, 4, 2, 2, 128, 8, false>::variant(),
-        Inst<4, 4, 4, 1, 64, 16, false>::variant(),
-        Inst<16, 4, 4, 1, 32, 16, true>::variant(),
-        Inst<8, 4, 4, 1, 32, 16, true>::variant(),
-        Inst<4, 4, 4, 1, 32, 16, true>::variant(),
+        InstSmall<32, 16, 6>::variant(),
+        InstSmall<16, 12, 4>::variant(),
+        InstSmall<16, 16, 6>::variant(),
+        InstSmall<16, 16, 4>::variant(),
+        Inst<32, 16, 4, 1, 32, false>::variant(),
+        Inst<16, 16, 4, 1, 32, false>::variant(),
+        Inst<16, 16, 4, 1, 64, false>::variant(),
+        Inst<16, 12, 4, 1, 32, false>::variant(),
+        Inst<8, 8, 4, 1, 32, false>::variant(),
+        Inst<8, 8, 4, 1, 64, false>::variant(),
+        Inst<8, 4, 2, 2, 128, false>::variant(),
+        Inst<8, 4, 4, 1, 64, false>::variant(),
+        Inst<4, 4, 2, 2, 128, false>::variant(),
+        Inst<4, 4, 4, 1, 64, false>::variant(),
+        Inst<16, 4, 4, 1, 32, true>::variant(),
+        Inst<8, 4, 4, 1, 32, true>::variant(),
+        Inst<4, 4, 4, 1, 32, true>::variant(),
     };
     return v;
 }
@@ -76,14 +95,16 @@ const std::vector<KernelVariant>& variants() {
 // smallest padded pixel count wins; ties go to the larger output tile
 int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
     const auto& vs = variants();
+    const bool small = Cin < dodt::kCK;
     int best = -1;
     double best_cost = 1e300;
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
-        if (v.deconv != deconv || Cout % v.BN != 0 || Cin % v.CK != 0) continue;
+        if (v.deconv != deconv || v.small_cin != small || Cout % v.BN != 0) continue;
+        if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0)) continue;
         const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;
         // mild preference for more work per staged byte
-        const double cost = padded * (1.0 + 4.0 / (v.MTB * 32.0 / 32.0) / 100.0 + 1.0 / v.BN);
+        const double cost = padded * (1.0 + 0.04 / v.MTB + 1.0 / v.BN);
         if (cost < best_cost) { best_cost = cost; best = (int)i; }
     }
     return best;
@@ -373,7 +394,13 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
                 const float val = l.deconv ? w[((size_t)tap * cout + co) * cin + ci]
                                            : w[((size_t)tap * cin + ci) * cout + co];
                 const int nt = co / v.BN, n = co % v.BN, ch = ci / v.CK, c = ci % v.CK;
-                blocked[((((size_t)nt * nchunks + ch) * 9 + tap) * v.CK + c) * v.BN + n] = val;
+                size_t idx;
+                if (v.small_cin)   // [tap][c][n]
+                    idx = ((size_t)tap * v.CK + c) * v.BN + n;
+                else               // [n_tile][chunk][tap][h = c/4][n][s = c%4]
+                    idx = (((((size_t)nt * nchunks + ch) * 9 + tap) * 2 + c / 4) * v.BN + n) * 4 +
+                          c % 4;
+                blocked[idx] = val;
             }
     (void)ntiles;
     std::vector<float> scale(l.Cout), shift(l.Cout);
