@@ -6,10 +6,12 @@
 // slim.conv2d_transpose with batch-norm (inference form, no gamma, eps 1e-3) and
 // ReLU, no bias.
 //
-// Data layout in HBM: activations NHWC float32, one buffer per pyramid level;
-// the decoder's concat inputs are single buffers (conv_k | upconv_k side by
-// side in the channel dimension) that the two producing kernels write into
-// directly, so no concat copy exists.  Both frames of a pair are one batch.
+// Data layout in HBM: the network input and the returned feature map are NHWC
+// float32 (the reference's layout); every activation in between is channel-blocked
+// [frame][C/8][H][W][8] ("CB8", see conv_kernels.h), one buffer per pyramid level.
+// The decoder's concat inputs are single buffers whose channel planes the two
+// producing kernels write directly (conv_k -> planes 0.., upconv_k -> the planes
+// after them), so no concat copy exists.  Both frames of a pair are one batch.
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -114,29 +116,32 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
 // small HBM-bound helpers
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-maxpool2x2_kernel(const float* __restrict__ in, int H, int W, int C, int in_ld,
+maxpool2x2_kernel(const float* __restrict__ in, int H, int W, int planes,
                   long long in_frame_stride, float* __restrict__ out, int frames) {
-    // one lane per (output pixel, 4 channels); VALID 2x2 stride 2
-    const int OH = H / 2, OW = W / 2, G = C / 4;
+    // CB8 in / CB8 out; one lane per (plane, output pixel, half of the 8 channels);
+    // VALID 2x2 stride 2.  Reads the first `planes` planes of the (wider) input.
+    const int OH = H / 2, OW = W / 2;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)frames * OH * OW * G;
+    const long long total = (long long)frames * planes * OH * OW * 2;
     if (t >= total) return;
-    const int g = (int)(t % G);
-    long long r = t / G;
+    const int g = (int)(t & 1);
+    long long r = t >> 1;
     const int ox = (int)(r % OW); r /= OW;
-    const int oy = (int)(r % OH);
-    const int f = (int)(r / OH);
-    const float* p = in + (size_t)f * in_frame_stride + ((size_t)(2 * oy) * W + 2 * ox) * in_ld + g * 4;
+    const int oy = (int)(r % OH); r /= OH;
+    const int pl = (int)(r % planes);
+    const int f = (int)(r / planes);
+    const float* p = in + (size_t)f * in_frame_stride + (size_t)pl * H * W * 8 +
+                     ((size_t)(2 * oy) * W + 2 * ox) * 8 + g * 4;
     const float4 a = *reinterpret_cast<const float4*>(p);
-    const float4 b = *reinterpret_cast<const float4*>(p + in_ld);
-    const float4 c = *reinterpret_cast<const float4*>(p + (size_t)W * in_ld);
-    const float4 d = *reinterpret_cast<const float4*>(p + (size_t)W * in_ld + in_ld);
+    const float4 b = *reinterpret_cast<const float4*>(p + 8);
+    const float4 c = *reinterpret_cast<const float4*>(p + (size_t)W * 8);
+    const float4 d = *reinterpret_cast<const float4*>(p + (size_t)W * 8 + 8);
     float4 o;
     o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
     o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
     o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
     o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
-    reinterpret_cast<float4*>(out)[t] = o;
+    reinterpret_cast<float4*>(out)[t] = o;   // out index == t by construction
 }
 
 // 1x1 conv to one channel + batch-norm + ReLU; 8 lanes per pixel, float4 each
@@ -240,6 +245,11 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
     a.tiles_y = dodt::ceil_div(l.H, v.TH);
     a.relu = 1;
     a.out_y0 = out_y0;
+    a.out_nhwc = override_out ? 1 : 0;
+    {
+        static const int dbg = getenv("DODT_CONV_DEBUG") ? atoi(getenv("DODT_CONV_DEBUG")) : 0;
+        a.debug = dbg;
+    }
     dim3 grid(a.tiles_x * a.tiles_y * ex->batch, l.Cout / v.BN);
     v.launch(a, grid, ex->ctx->stream);
     DODT_LAUNCH_CHECK();
@@ -249,9 +259,10 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
 int run_pool(dodt_extractor* ex, int src, int dst) {
     const Buffer& s = ex->buf[src];
     const Buffer& d = ex->buf[dst];
-    const long long total = (long long)ex->batch * d.H * d.W * (d.C / 4);
+    const int planes = d.C / 8;
+    const long long total = (long long)ex->batch * planes * d.H * d.W * 2;
     hipLaunchKernelGGL(maxpool2x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       ex->ctx->stream, s.ptr, s.H, s.W, d.C, s.C, (long long)s.frame_floats(),
+                       ex->ctx->stream, s.ptr, s.H, s.W, planes, (long long)s.frame_floats(),
                        d.ptr, ex->batch);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
@@ -493,11 +504,21 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
     if (w) *w = ow;
     if (c) *c = l.Cout;
     if (!dst) return DODT_OK;
-    // strided channel slice -> dense host tensor (batch, oh, ow, Cout)
+    // CB8 planes [dst_coff/8, +Cout/8) of every frame -> dense NHWC host tensor
     DODT_HIP_CHECK(hipStreamSynchronize(ex->ctx->stream));
-    DODT_HIP_CHECK(hipMemcpy2D(dst, (size_t)l.Cout * sizeof(float), b.ptr + l.dst_coff,
-                               (size_t)b.C * sizeof(float), (size_t)l.Cout * sizeof(float),
-                               (size_t)ex->batch * oh * ow, hipMemcpyDeviceToHost));
+    const size_t plane = (size_t)oh * ow * 8;
+    const int planes = l.Cout / 8;
+    std::vector<float> tmp(plane * planes);
+    for (int f = 0; f < ex->batch; ++f) {
+        DODT_HIP_CHECK(hipMemcpy(tmp.data(),
+                                 b.ptr + (size_t)f * b.frame_floats() + (size_t)(l.dst_coff / 8) * plane,
+                                 tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        float* o = dst + (size_t)f * oh * ow * l.Cout;
+        for (int pl = 0; pl < planes; ++pl)
+            for (size_t px = 0; px < (size_t)oh * ow; ++px)
+                for (int k = 0; k < 8; ++k)
+                    o[px * l.Cout + pl * 8 + k] = tmp[pl * plane + px * 8 + k];
+    }
     return DODT_OK;
 }
 

@@ -3,45 +3,49 @@
 // Implicit GEMM, M = output pixels, N = output channels, K = 9 * Cin, computed
 // with v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain per output).
 //
+//   * Activations live in HBM channel-blocked: [frame][C/8][H][W][8] ("CB8").  K is
+//     walked in chunks of 8 input channels = one plane.  Per chunk the halo'd
+//     patch (TH+2) x (TW+2) x 8 is staged ONCE into LDS as [pixel][8 ch + 4 pad]:
+//     straight 16-byte copies of rows that are contiguous in HBM (an NHWC layout
+//     would touch 32 cache lines per wave load and use a quarter of each).  Each
+//     input element is fetched once per workgroup and then serves 9 taps x BN
+//     channels from LDS: the kernel is MFMA-bound, not HBM-bound.
 //   * A workgroup (4 waves, 256 threads) owns a TH x TW spatial tile of one
 //     frame and BN output channels.  TH x TW pixels = MTB "M-tiles" of 32 pixels
 //     (32/TW rows x TW columns each), stacked vertically.
-//   * K is walked in chunks of CK = 8 input channels.  Per chunk the halo'd input
-//     patch (TH+2) x (TW+2) x 8 is staged ONCE from NHWC global memory into LDS
-//     as [pixel][8 channels + 4 pad] (48-byte pixels: straight 16-byte copies,
-//     no transposition), plus the chunk's weights.  Each input element is
-//     fetched once per workgroup and then serves 9 taps x BN channels from LDS:
-//     the kernel is MFMA-bound, not HBM-bound.
 //   * The MFMA's two k-lanes (lane>>5) take channels (s, s+4), s = 0..3, so ONE
-//     ds_read_b128 per lane delivers the A operand of four consecutive MFMAs
+//     ds_read_b128 per lane delivers the pixel operand of four consecutive MFMAs
 //     (channels 4h..4h+3 of its pixel); the weights are pre-blocked on the host
-//     as [tap][h][n][4] so the B operand is one ds_read_b128 as well.  A tap costs
-//     MT + NT LDS reads for 4*MT*NT MFMAs of 64 cycles, and the reads of tap t+1
-//     are issued before the MFMAs of tap t (register double buffer).
+//     as [tap][h][n][4] so the weight operand is one ds_read_b128 as well.  A tap
+//     costs MT + NT LDS reads for 4*MT*NT MFMAs of 64 cycles.
 //   * The global loads of chunk c+1 are issued before the MFMAs of chunk c and
 //     land in registers; they are written to LDS after the chunk's last MFMA
 //     (T14 "issue early / write late"), so HBM/L2 latency hides under compute.
-//   * Epilogue: inference batch-norm (scale, shift) + ReLU on the accumulators,
-//     stored NHWC with a caller-given pixel stride / channel offset, so decoder
-//     concats are written in place.  For a fixed accumulator register 32 lanes
-//     write 32 consecutive channels of one pixel (128 B).
+//   * The weights are the MFMA's A operand and the pixels its B operand, so in the
+//     32x32 result a lane owns ONE pixel and 4 x 4 consecutive output channels:
+//     the epilogue (inference batch-norm scale/shift + ReLU) stores 16 bytes per
+//     lane, 1 KB contiguous per wave instruction in the CB8 output (channel-plane
+//     offset given by the caller, so decoder concats are written in place).  The
+//     last layer of a net can store NHWC instead (the layout of the public API).
 //   * Transposed conv (3x3, stride 2, SAME): M = INPUT pixels; the 9 taps fall
 //     into the 4 output-parity classes (4 + 2 + 2 + 1 taps), one accumulator tile
 //     per class; out[2i+py][2j+px].
-//   * conv3x3_small_cin_kernel handles the first layer (Cin = 6 or 4): planar
-//     LDS patch, ds_read_b32 fragments.
+//   * conv3x3_small_cin_kernel handles the first layer (Cin = 6 or 4, NHWC input
+//     as the API delivers it): planar LDS patch, ds_read_b32 fragments, CB8 out.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace dodt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // a true 4-register value (not the HIP struct)
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // 4 registers (not the HIP struct)
 
 struct ConvArgs {
-    const float* in;      // NHWC, pixel stride in_ld floats, first channel in_coff
-    float* out;           // NHWC, pixel stride out_ld floats, first channel out_coff
-    const float* w;       // blocked weights, see conv.hip block_weights()
+    const float* in;      // CB8 [C/8][H][W][8], first plane in_coff/8
+                          // (small-cin kernel: NHWC, pixel stride in_ld floats)
+    float* out;           // CB8, first plane out_coff/8; or NHWC (out_nhwc) with pixel
+                          // stride out_ld floats and first channel out_coff
+    const float* w;       // blocked weights, see conv.hip dodt_extractor_set_layer
     const float* scale;   // [Cout] batch-norm scale  (rsqrt(var + eps))
     const float* shift;   // [Cout] batch-norm shift  (beta - mean * scale)
     int H, W;             // spatial size of the GEMM's M grid (conv: output = input
@@ -51,10 +55,13 @@ struct ConvArgs {
     long long in_frame_stride, out_frame_stride;  // floats between frames
     int tiles_x, tiles_y;  // tiles per frame
     int relu;
-    int out_y0;  // conv only: rows < out_y0 are dropped, row y lands at y - out_y0
+    int out_y0;    // conv only: rows < out_y0 are dropped, row y lands at y - out_y0
+    int out_nhwc;  // 1: NHWC output (last layer), 0: CB8
+    int debug;     // ablation switches for tools/ (0 in production): 1 = no epilogue
+                   // stores, 2 = no global loads in the K loop, 4 = no MFMAs
 };
 
-constexpr int kCK = 8;        // input channels per K chunk
+constexpr int kCK = 8;          // input channels per K chunk = one CB8 plane
 constexpr int kPixStride = 12;  // floats per LDS pixel: 8 channels + 4 pad (48 B)
 
 template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
@@ -68,21 +75,55 @@ struct ConvCfg {
     static constexpr int kPatchFloats = PH * PW * kPixStride;
     static constexpr int kWFloats = 9 * kCK * BN;
     static constexpr int kLdsBytes = (kPatchFloats + kWFloats) * 4;
-    static constexpr int kPatchItems = PH * PW * 2;      // float4 per chunk
-    static constexpr int kWItems = kWFloats / 4;         // float4 per chunk
+    static constexpr int kPatchItems = PH * PW * 2;       // float4 per chunk
+    static constexpr int kWItems = kWFloats / 4;          // float4 per chunk
     static constexpr int NP = (kPatchItems + 255) / 256;  // per-thread prefetch regs
     static constexpr int NW = (kWItems + 255) / 256;
+    // accumulator registers per lane and the residency they allow (unified 512-entry
+    // VGPR+AGPR file per SIMD): ask the register allocator for that many waves
+    static constexpr int kAccRegs = (DECONV ? 4 : MT * NT) * 16;
+    static constexpr int kMinWaves = kAccRegs <= 32 ? 4 : kAccRegs <= 64 ? 3 : 2;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MTB % WM == 0 && (BN / 32) % WN == 0, "tile split");
     static_assert(!DECONV || (MT == 1 && NT == 1), "deconv: one M x N tile per wave");
 };
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+// D[row = output channel][col = pixel] += W[channel][k] * X[k][pixel]
+__device__ __forceinline__ f32x16 mfma32(float w, float x, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, c, 0, 0, 0);
+}
+
+// Batch-norm + ReLU + store of one 32(channel) x 32(pixel) accumulator tile.
+// Lane (li = pixel, lh): register group g = r>>2 holds channels c0 + 8g + 4lh + (r&3).
+__device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const f32x16& acc,
+                                           int c0, int lh, int y, int x, int out_w,
+                                           long long plane_stride, bool ok) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = c0 + 8 * g + 4 * lh;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = acc[4 * g + k] * sc[k] + sh[k];
+            v[k] = a.relu ? fmaxf(t, 0.0f) : t;
+        }
+        if (ok) {
+            float* dst;
+            if (a.out_nhwc)
+                dst = out + ((size_t)y * out_w + x) * a.out_ld + a.out_coff + c;
+            else
+                dst = out + (size_t)((a.out_coff + c) >> 3) * plane_stride +
+                      ((size_t)y * out_w + x) * 8 + 4 * lh;
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    }
 }
 
 template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
-__global__ void __launch_bounds__(256)
+__global__ void
+__launch_bounds__(256, (ConvCfg<TW, MTB, WM, WN, BN, DECONV>::kMinWaves))
 conv3x3_mfma_kernel(const ConvArgs a) {
     using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
     constexpr int TH = Cfg::TH, PW = Cfg::PW;
@@ -106,8 +147,9 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     const int ty0 = (bid / a.tiles_x) * TH, tx0 = (bid % a.tiles_x) * TW;
     const int ntile = blockIdx.y;
     const int nchunks = a.Cin / kCK;
+    const int in_plane = a.H * a.W * 8;  // floats per input plane
 
-    const float* in = a.in + (size_t)frame * a.in_frame_stride;
+    const float* in = a.in + (size_t)frame * a.in_frame_stride + (size_t)(a.in_coff >> 3) * in_plane;
     const f32x4* wblk =
         reinterpret_cast<const f32x4*>(a.w + (size_t)ntile * nchunks * Cfg::kWFloats);
 
@@ -117,13 +159,12 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
 
-    // per-thread staging slots: patch item t -> (pixel p, half g).  Offsets are kept
-    // in scalar-indexed registers (loops fully unrolled, no address-taken arrays).
-    // Loads are unconditional (halo / surplus items read a valid dummy address and
-    // are zeroed or skipped at LDS-write time): a load under a branch would make
-    // hipcc wait for it on the spot.
+    // Per-thread staging slots: patch item t -> (pixel p, half g).  Loads are
+    // unconditional (halo / surplus items read a valid dummy address and are zeroed
+    // or skipped at LDS-write time): a load under a branch would make hipcc wait for
+    // it on the spot.
     int p_lds[NP];  // float offset in sP, or -1 (no item)
-    int p_glb[NP];  // float offset in `in` of the chunk's channel 0 (0 when padded)
+    int p_glb[NP];  // float offset inside a plane (0 when padded)
     unsigned p_ok = 0;  // bit k: item k reads real data (else zero padding)
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -136,53 +177,56 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
             p_lds[k] = p * PS + 4 * g;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                p_glb[k] = (gy * a.W + gx) * a.in_ld + a.in_coff + 4 * g;
+                p_glb[k] = (gy * a.W + gx) * 8 + 4 * g;
                 p_ok |= 1u << k;
             }
         }
     }
     f32x4 pre_p[NP], pre_w[NW];
-#define DODT_ISSUE_LOADS(CH)                                                              \
-    {                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < NP; ++k)                                    \
-            pre_p[k] = *reinterpret_cast<const f32x4*>(in + p_glb[k] + (CH) * kCK);       \
-        _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                  \
-            const int t = tid + k * 256;                                                  \
-            pre_w[k] = wblk[(size_t)(CH) * Cfg::kWItems + min(t, Cfg::kWItems - 1)];     \
-        }                                                                                 \
+#define DODT_ISSUE_LOADS(CH)                                                                  \
+    {                                                                                         \
+        const float* plane_ = in + (size_t)(CH) * in_plane;                                   \
+        _Pragma("unroll") for (int k = 0; k < NP; ++k)                                        \
+            pre_p[k] = *reinterpret_cast<const f32x4*>(plane_ + p_glb[k]);                    \
+        _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                      \
+            const int t = tid + k * 256;                                                      \
+            pre_w[k] = wblk[(size_t)(CH) * Cfg::kWItems + min(t, Cfg::kWItems - 1)];          \
+        }                                                                                     \
     }
-#define DODT_WRITE_LDS()                                                                  \
-    {                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < NP; ++k)                                    \
-            if (p_lds[k] >= 0)                                                            \
-                *reinterpret_cast<f32x4*>(sP + p_lds[k]) =                                \
-                    ((p_ok >> k) & 1u) ? pre_p[k] : f32x4{0.f, 0.f, 0.f, 0.f};            \
-        _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                  \
-            const int t = tid + k * 256;                                                  \
-            if (t < Cfg::kWItems) reinterpret_cast<f32x4*>(sW)[t] = pre_w[k];            \
-        }                                                                                 \
+#define DODT_WRITE_LDS()                                                                      \
+    {                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < NP; ++k)                                        \
+            if (p_lds[k] >= 0)                                                                \
+                *reinterpret_cast<f32x4*>(sP + p_lds[k]) =                                    \
+                    ((p_ok >> k) & 1u) ? pre_p[k] : f32x4{0.f, 0.f, 0.f, 0.f};                \
+        _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                      \
+            const int t = tid + k * 256;                                                      \
+            if (t < Cfg::kWItems) reinterpret_cast<f32x4*>(sW)[t] = pre_w[k];                 \
+        }                                                                                     \
     }
 
     // lane bases (floats)
-    const int a_base =
+    const int x_base =
         ((li / TW + wm * MT * Cfg::kRowsPerMT) * PW + (li % TW)) * PS + 4 * lh;
-    const int b_base = (lh * BN + wn * NT * 32 + li) * 4;
+    const int w_base = (lh * BN + wn * NT * 32 + li) * 4;
 
     DODT_ISSUE_LOADS(0)
     DODT_WRITE_LDS()
     __syncthreads();
 
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) DODT_ISSUE_LOADS(ch + 1)  // in flight during the MFMAs below
-        if constexpr (!DECONV) {
-            f32x4 af[2][MT], bf[2][NT];
+        if (ch + 1 < nchunks && !(a.debug & 2)) DODT_ISSUE_LOADS(ch + 1)  // in flight below
+        if (a.debug & 4) {
+            // ablation: no MFMAs
+        } else if constexpr (!DECONV) {
+            f32x4 xf[2][MT], wf[2][NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                af[0][mt] = *reinterpret_cast<const f32x4*>(
-                    sP + a_base + (mt * Cfg::kRowsPerMT * PW) * PS);
+                xf[0][mt] = *reinterpret_cast<const f32x4*>(
+                    sP + x_base + (mt * Cfg::kRowsPerMT * PW) * PS);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                bf[0][nt] = *reinterpret_cast<const f32x4*>(sW + b_base + nt * 128);
+                wf[0][nt] = *reinterpret_cast<const f32x4*>(sW + w_base + nt * 128);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int cur = tap & 1, nxt = cur ^ 1;
@@ -190,29 +234,25 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                     const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        af[nxt][mt] = *reinterpret_cast<const f32x4*>(
-                            sP + a_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);
+                        xf[nxt][mt] = *reinterpret_cast<const f32x4*>(
+                            sP + x_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        bf[nxt][nt] = *reinterpret_cast<const f32x4*>(
-                            sW + b_base + (tap + 1) * 2 * BN * 4 + nt * 128);
+                        wf[nxt][nt] = *reinterpret_cast<const f32x4*>(
+                            sW + w_base + (tap + 1) * 2 * BN * 4 + nt * 128);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
+                        for (int nt = 0; nt < NT; ++nt)
                             acc[mt * NT + nt] =
-                                mfma32(af[cur][mt][s], bf[cur][nt][s], acc[mt * NT + nt]);
-                        }
-                // keep the next tap's LDS reads ahead of this tap's MFMAs
-                if (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
+                                mfma32(wf[cur][nt][s], xf[cur][mt][s], acc[mt * NT + nt]);
             }
         } else {
             // patch origin is (ty0-1, tx0-1): in[i][j] sits at patch (r+1, c+1)
-            const float* pa = sP + a_base;
+            const float* pa = sP + x_base;
             const f32x4 a00 = *reinterpret_cast<const f32x4*>(pa + (PW + 1) * PS);  // in[i][j]
             const f32x4 a10 = *reinterpret_cast<const f32x4*>(pa + 1 * PS);         // in[i-1][j]
             const f32x4 a01 = *reinterpret_cast<const f32x4*>(pa + PW * PS);        // in[i][j-1]
@@ -220,20 +260,20 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             f32x4 bw[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
-                bw[tap] = *reinterpret_cast<const f32x4*>(sW + b_base + tap * 2 * BN * 4);
-#define DODT_DECONV_STEP(S)                                   \
-            acc[0] = mfma32(a00.S, bw[0].S, acc[0]);          \
-            acc[1] = mfma32(a00.S, bw[1].S, acc[1]);          \
-            acc[2] = mfma32(a00.S, bw[3].S, acc[2]);          \
-            acc[3] = mfma32(a00.S, bw[4].S, acc[3]);          \
-            acc[0] = mfma32(a10.S, bw[6].S, acc[0]);          \
-            acc[1] = mfma32(a10.S, bw[7].S, acc[1]);          \
-            acc[2] = mfma32(a01.S, bw[5].S, acc[2]);          \
-            acc[0] = mfma32(a01.S, bw[2].S, acc[0]);          \
-            acc[0] = mfma32(a11.S, bw[8].S, acc[0]);
+                bw[tap] = *reinterpret_cast<const f32x4*>(sW + w_base + tap * 2 * BN * 4);
             // taps indexed ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj]*w[ky][kx]
-            DODT_DECONV_STEP(x) DODT_DECONV_STEP(y) DODT_DECONV_STEP(z) DODT_DECONV_STEP(w)
-#undef DODT_DECONV_STEP
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = mfma32(bw[0][s], a00[s], acc[0]);
+                acc[1] = mfma32(bw[1][s], a00[s], acc[1]);
+                acc[2] = mfma32(bw[3][s], a00[s], acc[2]);
+                acc[3] = mfma32(bw[4][s], a00[s], acc[3]);
+                acc[0] = mfma32(bw[6][s], a10[s], acc[0]);
+                acc[1] = mfma32(bw[7][s], a10[s], acc[1]);
+                acc[2] = mfma32(bw[5][s], a01[s], acc[2]);
+                acc[0] = mfma32(bw[2][s], a01[s], acc[0]);
+                acc[0] = mfma32(bw[8][s], a11[s], acc[0]);
+            }
         }
         if (ch + 1 < nchunks) {
             __syncthreads();  // every wave is done reading this chunk
@@ -241,57 +281,41 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             __syncthreads();
         }
     }
-
 #undef DODT_ISSUE_LOADS
 #undef DODT_WRITE_LDS
-    // ---- epilogue: batch-norm + ReLU, NHWC store -------------------------------------
+
+    // ---- epilogue ------------------------------------------------------------------------
     float* out = a.out + (size_t)frame * a.out_frame_stride;
+    const bool st = !(a.debug & 1);
     if constexpr (!DECONV) {
+        const int out_rows = a.H - a.out_y0;
+        const long long plane = (long long)out_rows * a.W * 8;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = ntile * BN + (wn * NT + nt) * 32 + li;
-            const float sc = a.scale[co], sh = a.shift[co];
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
+            const int x = tx0 + li % TW;
+            const bool ok = st && y < a.H && x < a.W && y >= a.out_y0;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + m / TW;
-                    const int x = tx0 + m % TW;
-                    if (y < a.H && x < a.W && y >= a.out_y0) {
-                        float v = acc[mt * NT + nt][r] * sc + sh;
-                        if (a.relu) v = fmaxf(v, 0.0f);
-                        out[((size_t)(y - a.out_y0) * a.W + x) * a.out_ld + a.out_coff + co] = v;
-                    }
-                }
-            }
+            for (int nt = 0; nt < NT; ++nt)
+                store_tile(a, out, acc[mt * NT + nt], ntile * BN + (wn * NT + nt) * 32, lh,
+                           y - a.out_y0, x, a.W, plane, ok);
         }
     } else {
-        const int co = ntile * BN + wn * 32 + li;
-        const float sc = a.scale[co], sh = a.shift[co];
-        const int OW = 2 * a.W;
+        const int y = ty0 + wm * Cfg::kRowsPerMT + li / TW;
+        const int x = tx0 + li % TW;
+        const bool ok = st && y < a.H && x < a.W;
+        const long long plane = (long long)(2 * a.H) * (2 * a.W) * 8;
 #pragma unroll
-        for (int cls = 0; cls < 4; ++cls) {
-            const int py = cls >> 1, px = cls & 1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int y = ty0 + wm * Cfg::kRowsPerMT + m / TW;
-                const int x = tx0 + m % TW;
-                if (y < a.H && x < a.W) {
-                    float v = acc[cls][r] * sc + sh;
-                    if (a.relu) v = fmaxf(v, 0.0f);
-                    out[((size_t)(2 * y + py) * OW + (2 * x + px)) * a.out_ld + a.out_coff + co] = v;
-                }
-            }
-        }
+        for (int cls = 0; cls < 4; ++cls)
+            store_tile(a, out, acc[cls], ntile * BN + wn * 32, lh, 2 * y + (cls >> 1),
+                       2 * x + (cls & 1), 2 * a.W, plane, ok);
     }
 }
 
 // ---------------------------------------------------------------------------
-// First layer (Cin = 6 for BEV, 4 for the padded image): one chunk of CK = Cin
-// channels, planar LDS patch [CK][PH*PW (+pad)], weights [9][CK][32], scalar
-// ds_read_b32 fragments.  1.5 % of the FLOPs.
+// First layer (Cin = 6 for BEV, 4 for the padded image): NHWC input, one chunk of
+// CK = Cin channels, planar LDS patch [CK][PH*PW (+pad)], weights [9][CK][32],
+// scalar ds_read_b32 fragments, CB8 output.  1.5 % of the FLOPs.
 // ---------------------------------------------------------------------------
 template <int TW, int MTB, int CK>
 struct SmallCfg {
@@ -360,36 +384,29 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
         for (int t = tid; t < Cfg::kWFloats / 4; t += 256) reinterpret_cast<float4*>(sW)[t] = src[t];
     }
     __syncthreads();
-    const int a_base = lh * PS + (li / TW) * PW + (li % TW) + wm * MT * Cfg::kRowsPerMT * PW;
-    const int b_base = lh * BN + li;
+    const int x_base = lh * PS + (li / TW) * PW + (li % TW) + wm * MT * Cfg::kRowsPerMT * PW;
+    const int w_base = lh * BN + li;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
-            const float bfv = sW[b_base + (tap * CK + 2 * cp) * BN];
+            const float wv = sW[w_base + (tap * CK + 2 * cp) * BN];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float afv = sP[a_base + 2 * cp * PS + (mt * Cfg::kRowsPerMT + ky) * PW + kx];
-                acc[mt] = mfma32(afv, bfv, acc[mt]);
+                const float xv = sP[x_base + 2 * cp * PS + (mt * Cfg::kRowsPerMT + ky) * PW + kx];
+                acc[mt] = mfma32(wv, xv, acc[mt]);
             }
         }
     }
     float* out = a.out + (size_t)frame * a.out_frame_stride;
-    const float sc = a.scale[li], sh = a.shift[li];
+    const long long plane = (long long)a.H * a.W * 8;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + m / TW;
-            const int x = tx0 + m % TW;
-            if (y < a.H && x < a.W) {
-                float v = acc[mt][r] * sc + sh;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                out[((size_t)y * a.W + x) * a.out_ld + a.out_coff + li] = v;
-            }
-        }
+    for (int mt = 0; mt < MT; ++mt) {
+        const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
+        const int x = tx0 + li % TW;
+        store_tile(a, out, acc[mt], 0, lh, y, x, a.W, plane, y < a.H && x < a.W);
+    }
 }
 
 }  // namespace dodt
