@@ -31,6 +31,7 @@ struct KernelVariant {
     int TW, MTB, WM, WN, BN, CK;
     bool deconv, small_cin;
     int TH, lds_bytes;
+    int blocks_per_cu;  // resident workgroups per CU (registers and LDS permitting)
     void (*launch)(const ConvArgs&, dim3 grid, hipStream_t s);
     hipError_t (*prepare)();
 };
@@ -48,8 +49,11 @@ struct Inst {
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
     }
     static KernelVariant variant() {
+        int per_cu = Cfg::kMinWaves;  // one wave of each workgroup per SIMD
+        const int by_lds = (160 * 1024) / Cfg::kLdsBytes;
+        if (per_cu > by_lds) per_cu = by_lds;
         return KernelVariant{TW, MTB, WM, WN, BN, dodt::kCK, DECONV, false, Cfg::TH,
-                             Cfg::kLdsBytes, &launch, &prepare};
+                             Cfg::kLdsBytes, per_cu, &launch, &prepare};
     }
 };
 
@@ -66,7 +70,7 @@ struct InstSmall {
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
     }
     static KernelVariant variant() {
-        return KernelVariant{TW, MTB, 4, 1, 32, CK, false, true, Cfg::TH, Cfg::kLdsBytes,
+        return KernelVariant{TW, MTB, 4, 1, 32, CK, false, true, Cfg::TH, Cfg::kLdsBytes, 4,
                              &launch, &prepare};
     }
 };
@@ -79,7 +83,7 @@ const std::vector<KernelVariant>& variants() {
         InstSmall<16, 16, 4>::variant(),
         Inst<32, 16, 4, 1, 32, false>::variant(),
         Inst<16, 16, 4, 1, 32, false>::variant(),
-        Inst<16, 16, 4, 1, 64, false>::variant(),
+        Inst<16, 8, 4, 1, 64, false>::variant(),
         Inst<16, 12, 4, 1, 32, false>::variant(),
         Inst<8, 8, 4, 1, 32, false>::variant(),
         Inst<8, 8, 4, 1, 64, false>::variant(),
@@ -250,7 +254,15 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
         static const int dbg = getenv("DODT_CONV_DEBUG") ? atoi(getenv("DODT_CONV_DEBUG")) : 0;
         a.debug = dbg;
     }
-    dim3 grid(a.tiles_x * a.tiles_y * ex->batch, l.Cout / v.BN);
+    a.n_tiles = l.Cout / v.BN;
+    a.n_items = a.tiles_x * a.tiles_y * ex->batch * a.n_tiles;
+    // persistent workgroups: as many as stay resident, each walks items with that stride
+    int grid_x = a.n_items;
+    if (!v.small_cin) {
+        const int resident = ex->ctx->num_cus * v.blocks_per_cu;
+        if (grid_x > resident) grid_x = resident;
+    }
+    dim3 grid(grid_x, 1);
     v.launch(a, grid, ex->ctx->stream);
     DODT_LAUNCH_CHECK();
     return DODT_OK;

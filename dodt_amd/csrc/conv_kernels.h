@@ -18,9 +18,12 @@
 //     (channels 4h..4h+3 of its pixel); the weights are pre-blocked on the host
 //     as [tap][h][n][4] so the weight operand is one ds_read_b128 as well.  A tap
 //     costs MT + NT LDS reads for 4*MT*NT MFMAs of 64 cycles.
-//   * The global loads of chunk c+1 are issued before the MFMAs of chunk c and
-//     land in registers; they are written to LDS after the chunk's last MFMA
-//     (T14 "issue early / write late"), so HBM/L2 latency hides under compute.
+//   * Software pipeline, one barrier per chunk: the global loads of chunk c+2 are
+//     issued (into registers) before the MFMAs of chunk c, and chunk c+1 is written
+//     to the other LDS buffer at the top of step c (T14 "issue early / write
+//     late"), so HBM/L2 latency and the LDS writes hide under the MFMAs.  Workgroups
+//     are persistent and the chunk sequence runs across their work items, so an
+//     item's first loads and its epilogue stores are covered as well.
 //   * The weights are the MFMA's A operand and the pixels its B operand, so in the
 //     32x32 result a lane owns ONE pixel and 4 x 4 consecutive output channels:
 //     the epilogue (inference batch-norm scale/shift + ReLU) stores 16 bytes per
@@ -53,7 +56,9 @@ struct ConvArgs {
     int Cin, Cout;
     int in_ld, in_coff, out_ld, out_coff;
     long long in_frame_stride, out_frame_stride;  // floats between frames
-    int tiles_x, tiles_y;  // tiles per frame
+    int tiles_x, tiles_y;  // spatial tiles per frame
+    int n_tiles;           // Cout / BN
+    int n_items;           // frames * n_tiles * tiles_x * tiles_y
     int relu;
     int out_y0;    // conv only: rows < out_y0 are dropped, row y lands at y - out_y0
     int out_nhwc;  // 1: NHWC output (last layer), 0: CB8
@@ -74,7 +79,8 @@ struct ConvCfg {
     static constexpr int NT = BN / 32 / WN;
     static constexpr int kPatchFloats = PH * PW * kPixStride;
     static constexpr int kWFloats = 9 * kCK * BN;
-    static constexpr int kLdsBytes = (kPatchFloats + kWFloats) * 4;
+    static constexpr int kBufFloats = kPatchFloats + kWFloats;  // one chunk: patch | weights
+    static constexpr int kLdsBytes = 2 * kBufFloats * 4;         // double buffered
     static constexpr int kPatchItems = PH * PW * 2;       // float4 per chunk
     static constexpr int kWItems = kWFloats / 4;          // float4 per chunk
     static constexpr int NP = (kPatchItems + 255) / 256;  // per-thread prefetch regs
@@ -82,7 +88,9 @@ struct ConvCfg {
     // accumulator registers per lane and the residency they allow (unified 512-entry
     // VGPR+AGPR file per SIMD): ask the register allocator for that many waves
     static constexpr int kAccRegs = (DECONV ? 4 : MT * NT) * 16;
-    static constexpr int kMinWaves = kAccRegs <= 32 ? 4 : kAccRegs <= 64 ? 3 : 2;
+    // persistent workgroups hide their own prologue/epilogue, so two per CU suffice:
+    // give the register allocator the full 256-register budget of 2 waves per SIMD
+    static constexpr int kMinWaves = 2;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MTB % WM == 0 && (BN / 32) % WN == 0, "tile split");
     static_assert(!DECONV || (MT == 1 && NT == 1), "deconv: one M x N tile per wave");
@@ -132,76 +140,84 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int PS = kPixStride;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sP = smem;                      // [PH*PW][12]
-    float* sW = smem + Cfg::kPatchFloats;  // [9][2][BN][4]
+    float* sP = smem;                      // buffer b: [PH*PW][12] at + b * kBufFloats
+    float* sW = smem + Cfg::kPatchFloats;  //           [9][2][BN][4] behind it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-
-    int bid = blockIdx.x;
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int frame = bid / tiles;
-    bid -= frame * tiles;
-    const int ty0 = (bid / a.tiles_x) * TH, tx0 = (bid % a.tiles_x) * TW;
-    const int ntile = blockIdx.y;
     const int nchunks = a.Cin / kCK;
     const int in_plane = a.H * a.W * 8;  // floats per input plane
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int items_per_frame = tiles * a.n_tiles;
 
-    const float* in = a.in + (size_t)frame * a.in_frame_stride + (size_t)(a.in_coff >> 3) * in_plane;
-    const f32x4* wblk =
-        reinterpret_cast<const f32x4*>(a.w + (size_t)ntile * nchunks * Cfg::kWFloats);
+    // Persistent workgroup: work item = (frame, n-tile, spatial tile), walked with
+    // stride gridDim.x.  The loads of the next item's first chunk are issued during
+    // the last chunk of the current one and the epilogue's stores drain under the next
+    // item's MFMAs, so the matrix pipe never waits for a workgroup to start or end.
+    struct Item { int frame, ntile, ty0, tx0; };
+    auto decode = [&](int it) {
+        Item r;
+        r.frame = it / items_per_frame;
+        it -= r.frame * items_per_frame;
+        r.ntile = it / tiles;
+        it -= r.ntile * tiles;
+        r.ty0 = (it / a.tiles_x) * TH;
+        r.tx0 = (it % a.tiles_x) * TW;
+        return r;
+    };
 
-    f32x16 acc[NACC];
+    // Per-thread staging slots: patch slot k = item (tid + 256 k) -> (pixel p, half g).
+    // Loads are unconditional (halo / surplus slots read a valid dummy address and are
+    // zeroed or skipped at LDS-write time): a load under a branch would make hipcc wait
+    // for it on the spot.  Slot geometry is recomputed where needed (a few VALU ops)
+    // rather than kept in registers across the whole kernel.
+    int p_glb[NP];        // float offset inside a plane (0 when padded), current load item
+    unsigned p_ok = 0;    // bit k: slot k of the data now in pre_p is real (else zero pad)
+    unsigned p_ok_next = 0;
+    const float* in_item = a.in;  // plane 0 of the load item's input
+    const f32x4* w_item = reinterpret_cast<const f32x4*>(a.w);
+    auto setup_loads = [&](const Item& it) {
+        p_ok_next = 0;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-
-    // Per-thread staging slots: patch item t -> (pixel p, half g).  Loads are
-    // unconditional (halo / surplus items read a valid dummy address and are zeroed
-    // or skipped at LDS-write time): a load under a branch would make hipcc wait for
-    // it on the spot.
-    int p_lds[NP];  // float offset in sP, or -1 (no item)
-    int p_glb[NP];  // float offset inside a plane (0 when padded)
-    unsigned p_ok = 0;  // bit k: item k reads real data (else zero padding)
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int t = tid + k * 256;
-        p_lds[k] = -1;
-        p_glb[k] = 0;
-        if (t < Cfg::kPatchItems) {
+        for (int k = 0; k < NP; ++k) {
+            const int t = tid + k * 256;
             const int g = t & 1, p = t >> 1;
             const int py = p / PW, px = p - py * PW;
-            const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-            p_lds[k] = p * PS + 4 * g;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                p_glb[k] = (gy * a.W + gx) * 8 + 4 * g;
-                p_ok |= 1u << k;
-            }
+            const int gy = it.ty0 - 1 + py, gx = it.tx0 - 1 + px;
+            const bool ok = t < Cfg::kPatchItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            p_glb[k] = ok ? (gy * a.W + gx) * 8 + g * 4 : 0;
+            p_ok_next |= (ok ? 1u : 0u) << k;
         }
-    }
+        in_item = a.in + (size_t)it.frame * a.in_frame_stride +
+                  (size_t)(a.in_coff >> 3) * in_plane;
+        w_item = reinterpret_cast<const f32x4*>(a.w + (size_t)it.ntile * nchunks * Cfg::kWFloats);
+    };
     f32x4 pre_p[NP], pre_w[NW];
 #define DODT_ISSUE_LOADS(CH)                                                                  \
     {                                                                                         \
-        const float* plane_ = in + (size_t)(CH) * in_plane;                                   \
+        const float* plane_ = in_item + (size_t)(CH) * in_plane;                              \
         _Pragma("unroll") for (int k = 0; k < NP; ++k)                                        \
             pre_p[k] = *reinterpret_cast<const f32x4*>(plane_ + p_glb[k]);                    \
         _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                      \
             const int t = tid + k * 256;                                                      \
-            pre_w[k] = wblk[(size_t)(CH) * Cfg::kWItems + min(t, Cfg::kWItems - 1)];          \
+            pre_w[k] = w_item[(size_t)(CH) * Cfg::kWItems + min(t, Cfg::kWItems - 1)];        \
         }                                                                                     \
     }
-#define DODT_WRITE_LDS()                                                                      \
+#define DODT_WRITE_LDS(BUF)                                                                   \
     {                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < NP; ++k)                                        \
-            if (p_lds[k] >= 0)                                                                \
-                *reinterpret_cast<f32x4*>(sP + p_lds[k]) =                                    \
+        float* dP_ = sP + (BUF) * Cfg::kBufFloats;                                            \
+        float* dW_ = sW + (BUF) * Cfg::kBufFloats;                                            \
+        _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                      \
+            const int t = tid + k * 256;                                                      \
+            if (t < Cfg::kPatchItems)                                                         \
+                *reinterpret_cast<f32x4*>(dP_ + (t >> 1) * PS + (t & 1) * 4) =                \
                     ((p_ok >> k) & 1u) ? pre_p[k] : f32x4{0.f, 0.f, 0.f, 0.f};                \
+        }                                                                                     \
         _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                      \
             const int t = tid + k * 256;                                                      \
-            if (t < Cfg::kWItems) reinterpret_cast<f32x4*>(sW)[t] = pre_w[k];                 \
+            if (t < Cfg::kWItems) reinterpret_cast<f32x4*>(dW_)[t] = pre_w[k];                \
         }                                                                                     \
     }
 
@@ -210,12 +226,60 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         ((li / TW + wm * MT * Cfg::kRowsPerMT) * PW + (li % TW)) * PS + 4 * lh;
     const int w_base = (lh * BN + wn * NT * 32 + li) * 4;
 
+    // ---- flat pipeline over (item, chunk) steps --------------------------------------------
+    //   step k:  [write chunk k+1 (in registers since step k-1) to LDS buffer (k+1)&1]
+    //            [issue the global loads of chunk k+2]  [MFMAs of chunk k from buffer k&1]
+    //            [epilogue if chunk k ends an item]  [ONE barrier]
+    // The chunk sequence runs across item boundaries, so neither the first loads of an
+    // item nor its stores ever leave the matrix pipe idle.
+    if ((int)blockIdx.x >= a.n_items) return;  // uniform per workgroup
+    int load_item = blockIdx.x, load_ch = 0;   // next chunk to issue loads for
+    int comp_item = blockIdx.x, comp_ch = 0;   // chunk the MFMAs work on
+    bool regs_full = false;
+    unsigned regs_ok = 0;                       // zero-pad mask of the data in pre_p
+    setup_loads(decode(load_item));
+#define DODT_ADVANCE_LOAD()                                                                   \
+    {                                                                                         \
+        if (++load_ch == nchunks) {                                                           \
+            load_ch = 0;                                                                      \
+            load_item += gridDim.x;                                                           \
+            if (load_item < a.n_items) setup_loads(decode(load_item));                        \
+        }                                                                                     \
+    }
     DODT_ISSUE_LOADS(0)
-    DODT_WRITE_LDS()
+    regs_ok = p_ok_next;
+    DODT_ADVANCE_LOAD()
+    p_ok = regs_ok;
+    DODT_WRITE_LDS(0)
+    if (load_item < a.n_items && !(a.debug & 2)) {
+        DODT_ISSUE_LOADS(load_ch)
+        regs_ok = p_ok_next;
+        regs_full = true;
+        DODT_ADVANCE_LOAD()
+    }
     __syncthreads();
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks && !(a.debug & 2)) DODT_ISSUE_LOADS(ch + 1)  // in flight below
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+    int buf = 0;
+    while (comp_item < a.n_items) {
+        const float* bP = sP + buf * Cfg::kBufFloats;
+        const float* bW = sW + buf * Cfg::kBufFloats;
+        if (regs_full) {
+            p_ok = regs_ok;
+            DODT_WRITE_LDS(buf ^ 1)   // waits for loads issued one whole step ago
+            regs_full = false;
+        }
+        if (load_item < a.n_items && !(a.debug & 2)) {
+            DODT_ISSUE_LOADS(load_ch)  // in flight during the MFMAs below
+            regs_ok = p_ok_next;
+            regs_full = true;
+            DODT_ADVANCE_LOAD()
+        }
         if (a.debug & 4) {
             // ablation: no MFMAs
         } else if constexpr (!DECONV) {
@@ -223,24 +287,27 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 xf[0][mt] = *reinterpret_cast<const f32x4*>(
-                    sP + x_base + (mt * Cfg::kRowsPerMT * PW) * PS);
+                    bP + x_base + (mt * Cfg::kRowsPerMT * PW) * PS);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                wf[0][nt] = *reinterpret_cast<const f32x4*>(sW + w_base + nt * 128);
+                wf[0][nt] = *reinterpret_cast<const f32x4*>(bW + w_base + nt * 128);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int cur = tap & 1, nxt = cur ^ 1;
+                const int cb = tap & 1, nb = cb ^ 1;
                 if (tap + 1 < 9) {
                     const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        xf[nxt][mt] = *reinterpret_cast<const f32x4*>(
-                            sP + x_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);
+                        xf[nb][mt] = *reinterpret_cast<const f32x4*>(
+                            bP + x_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        wf[nxt][nt] = *reinterpret_cast<const f32x4*>(
-                            sW + w_base + (tap + 1) * 2 * BN * 4 + nt * 128);
+                        wf[nb][nt] = *reinterpret_cast<const f32x4*>(
+                            bW + w_base + (tap + 1) * 2 * BN * 4 + nt * 128);
                 }
+                // the next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc would
+                // otherwise sink them below to save registers and expose their latency)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -248,11 +315,12 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt * NT + nt] =
-                                mfma32(wf[cur][nt][s], xf[cur][mt][s], acc[mt * NT + nt]);
+                                mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // patch origin is (ty0-1, tx0-1): in[i][j] sits at patch (r+1, c+1)
-            const float* pa = sP + x_base;
+            const float* pa = bP + x_base;
             const f32x4 a00 = *reinterpret_cast<const f32x4*>(pa + (PW + 1) * PS);  // in[i][j]
             const f32x4 a10 = *reinterpret_cast<const f32x4*>(pa + 1 * PS);         // in[i-1][j]
             const f32x4 a01 = *reinterpret_cast<const f32x4*>(pa + PW * PS);        // in[i][j-1]
@@ -260,8 +328,8 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             f32x4 bw[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
-                bw[tap] = *reinterpret_cast<const f32x4*>(sW + w_base + tap * 2 * BN * 4);
-            // taps indexed ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj]*w[ky][kx]
+                bw[tap] = *reinterpret_cast<const f32x4*>(bW + w_base + tap * 2 * BN * 4);
+            // taps ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj] * w[ky][kx]
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc[0] = mfma32(bw[0][s], a00[s], acc[0]);
@@ -275,41 +343,48 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                 acc[0] = mfma32(bw[8][s], a11[s], acc[0]);
             }
         }
-        if (ch + 1 < nchunks) {
-            __syncthreads();  // every wave is done reading this chunk
-            DODT_WRITE_LDS()
-            __syncthreads();
+        if (++comp_ch == nchunks) {
+            // ---- epilogue: the stores drain under the next item's MFMAs ---------------
+            const Item cur = decode(comp_item);
+            float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
+            const bool st = !(a.debug & 1);
+            if constexpr (!DECONV) {
+                const int out_rows = a.H - a.out_y0;
+                const long long plane = (long long)out_rows * a.W * 8;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int y = cur.ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
+                    const int x = cur.tx0 + li % TW;
+                    const bool ok = st && y < a.H && x < a.W && y >= a.out_y0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        store_tile(a, out, acc[mt * NT + nt],
+                                   cur.ntile * BN + (wn * NT + nt) * 32, lh, y - a.out_y0, x,
+                                   a.W, plane, ok);
+                }
+            } else {
+                const int y = cur.ty0 + wm * Cfg::kRowsPerMT + li / TW;
+                const int x = cur.tx0 + li % TW;
+                const bool ok = st && y < a.H && x < a.W;
+                const long long plane = (long long)(2 * a.H) * (2 * a.W) * 8;
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls)
+                    store_tile(a, out, acc[cls], cur.ntile * BN + wn * 32, lh,
+                               2 * y + (cls >> 1), 2 * x + (cls & 1), 2 * a.W, plane, ok);
+            }
+#pragma unroll
+            for (int k = 0; k < NACC; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+            comp_ch = 0;
+            comp_item += gridDim.x;
         }
+        __syncthreads();  // buffer buf^1 is complete, buffer buf is free
+        buf ^= 1;
     }
 #undef DODT_ISSUE_LOADS
 #undef DODT_WRITE_LDS
-
-    // ---- epilogue ------------------------------------------------------------------------
-    float* out = a.out + (size_t)frame * a.out_frame_stride;
-    const bool st = !(a.debug & 1);
-    if constexpr (!DECONV) {
-        const int out_rows = a.H - a.out_y0;
-        const long long plane = (long long)out_rows * a.W * 8;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
-            const int x = tx0 + li % TW;
-            const bool ok = st && y < a.H && x < a.W && y >= a.out_y0;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                store_tile(a, out, acc[mt * NT + nt], ntile * BN + (wn * NT + nt) * 32, lh,
-                           y - a.out_y0, x, a.W, plane, ok);
-        }
-    } else {
-        const int y = ty0 + wm * Cfg::kRowsPerMT + li / TW;
-        const int x = tx0 + li % TW;
-        const bool ok = st && y < a.H && x < a.W;
-        const long long plane = (long long)(2 * a.H) * (2 * a.W) * 8;
-#pragma unroll
-        for (int cls = 0; cls < 4; ++cls)
-            store_tile(a, out, acc[cls], ntile * BN + wn * 32, lh, 2 * y + (cls >> 1),
-                       2 * x + (cls & 1), 2 * a.W, plane, ok);
-    }
+#undef DODT_ADVANCE_LOAD
 }
 
 // ---------------------------------------------------------------------------
