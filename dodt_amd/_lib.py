@@ -53,6 +53,7 @@ SIGNATURES = {
     'dodt_ctx_create_on_stream': (_i, [_i, _vp, C.POINTER(_vp)]),
     'dodt_ctx_destroy': (_i, [_vp]),
     'dodt_ctx_sync': (_i, [_vp]),
+    'dodt_ctx_wait_for': (_i, [_vp, _vp]),
     'dodt_malloc': (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     'dodt_free': (_i, [_vp, _vp]),
     'dodt_memcpy_h2d': (_i, [_vp, _vp, _vp, C.c_size_t]),

@@ -69,6 +69,7 @@ static int ctx_create(int device_id, hipStream_t stream, bool external, dodt_ctx
     (void)hipEventCreate(&c->ev_stop);
     (void)hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 8 * 16 * sizeof(int32_t), 0);
     for (int i = 0; i < 8; ++i) (void)hipEventCreateWithFlags(&c->fetch_ev[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming);
     *out = c;
     return DODT_OK;
 }
@@ -91,6 +92,7 @@ int dodt_ctx_destroy(dodt_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < 8; ++i)
         if (ctx->fetch_ev[i]) (void)hipEventDestroy(ctx->fetch_ev[i]);
+    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -101,6 +103,14 @@ int dodt_ctx_destroy(dodt_ctx* ctx) {
 int dodt_ctx_sync(dodt_ctx* ctx) {
     DODT_REQUIRE(ctx, "dodt_ctx_sync: ctx is NULL");
     DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return DODT_OK;
+}
+
+int dodt_ctx_wait_for(dodt_ctx* ctx, dodt_ctx* other) {
+    DODT_REQUIRE(ctx && other, "dodt_ctx_wait_for: NULL argument");
+    if (ctx->stream == other->stream) return DODT_OK;
+    DODT_HIP_CHECK(hipEventRecord(other->join_ev, other->stream));
+    DODT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, other->join_ev, 0));
     return DODT_OK;
 }
 

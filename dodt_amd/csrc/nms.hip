@@ -25,7 +25,7 @@ namespace {
 constexpr int kTile = 8192;      // keys per LDS sort tile
 constexpr int kSortThreads = 1024;
 constexpr int kChunkRows = 2048; // candidate rows per mask chunk
-constexpr int kColGroup = 8;     // column blocks per wave in the mask kernel
+constexpr int kColGroup = 2;     // column blocks per wave in the mask kernel
 
 struct NmsState {   // lives in device memory next to the scratch arrays
     int count;      // boxes selected so far
@@ -256,14 +256,45 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restri
         const unsigned long long sel = s_sel;
         const int done = s_done;
         if (!done && sel != 0ull) {
-            for (int c = b + 1 + tid; c < nb; c += 1024) {
-                unsigned long long acc = 0ull, rest = sel;
-                while (rest != 0ull) {
-                    const int r = __ffsll((long long)rest) - 1;
-                    rest &= rest - 1ull;
-                    acc |= mask[(size_t)(b * 64 + r - row0) * nb + c];
+            // OR the selected rows of this block into `removed` for every later column
+            // block.  All 64 rows are loaded unconditionally and masked by `sel` (no
+            // branch around a load, so the loads of a thread are all in flight at once);
+            // the (row group, column) pairs are spread over the whole workgroup and
+            // combined with LDS atomics.
+            const int ncols = nb - (b + 1);
+            if (ncols > 0) {
+                const int groups = max(1, min(64, 1024 / ncols));  // row groups per column
+                const int c = b + 1 + tid % ncols;
+                const int g = tid / ncols;
+                if (g < groups) {
+                    const unsigned long long* base =
+                        mask + (size_t)(b * 64 - row0) * nb + c;
+                    unsigned long long acc = 0ull;
+                    for (int r0 = g; r0 < 64; r0 += groups * 8) {
+                        unsigned long long v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int r = min(r0 + k * groups, 63);
+                            v[k] = base[(size_t)r * nb];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int r = r0 + k * groups;
+                            if (r < 64 && ((sel >> r) & 1ull)) acc |= v[k];
+                        }
+                    }
+                    if (acc) atomicOr(&s_removed[c], acc);
                 }
-                s_removed[c] |= acc;
+                // columns beyond one workgroup pass (ncols > 1024)
+                for (int cc = b + 1 + 1024 + tid; cc < nb; cc += 1024) {
+                    unsigned long long acc = 0ull, rest = sel;
+                    while (rest != 0ull) {
+                        const int r = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1ull;
+                        acc |= mask[(size_t)(b * 64 + r - row0) * nb + cc];
+                    }
+                    s_removed[cc] |= acc;
+                }
             }
         }
         __syncthreads();

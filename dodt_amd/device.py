@@ -92,6 +92,10 @@ class Context(object):
     def sync(self):
         _lib.check(self.lib.dodt_ctx_sync(self.handle), 'dodt_ctx_sync')
 
+    def wait_for(self, other):
+        """Later work on this context waits for what `other` has enqueued so far."""
+        _lib.check(self.lib.dodt_ctx_wait_for(self.handle, other.handle), 'dodt_ctx_wait_for')
+
     def timer_start(self):
         _lib.check(self.lib.dodt_timer_start(self.handle), 'timer_start')
 

@@ -7,12 +7,20 @@ avod/core/models/dt_rpn_model.py:732-1042) then the graph
 crop and NMS (anchor predictor, stage-2 FC) are "next" rows of SURVEY 8(f): their
 outputs are inputs of this pipeline (`heads`), resident in HBM.
 
-Everything stays on the device; the only host round trip per pair is the pair of
-kept-anchor counts, fetched while the conv stacks run.
+Frame pairs are independent (batch size 1 in the reference, no cross-pair state),
+so a step may carry several pairs: all their frames go through the conv stacks as
+one batch (more workgroups per launch -> fewer idle CUs in the last wave of each
+layer), and the per-frame work before and after the convs runs on side streams,
+one frame each, so the single-workgroup stages (NMS scan) of different frames
+overlap.  Steps are software-pipelined two deep: while the conv stacks of step k
+run on the main streams, the side streams finish step k-1 (crops, decode, NMS);
+feature maps and per-frame buffers are double-buffered for that, and `finish()`
+drains the last step.  Everything stays on the device; the only host round trip
+per step is the kept-anchor count of each frame, fetched while the convs run.
 """
 import numpy as np
 
-from dodt_amd import _lib, ops, synth
+from dodt_amd import device, ops, synth
 from dodt_amd.core.anchor_generators import grid_anchor_3d_generator as gen
 from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr, ImgVggPyr
 
@@ -23,18 +31,25 @@ REC_COLS = 17            # dt_evaluator.py:1217-1257
 class FramePairPipeline(object):
     def __init__(self, ctx, cfg, p2=synth.P2, r0_rect=synth.R0_RECT,
                  tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
-                 n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None):
+                 n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None,
+                 pairs_per_step=1, side_streams=None):
         self.ctx = ctx
         self.cfg = cfg
         self.p2 = np.asarray(p2, dtype=np.float64)
         self.image_wh = tuple(image_wh)
         self.P = int(rpn_nms_size)
+        self.pairs = int(pairs_per_step)
+        self.nf = 2 * self.pairs                       # frames per step
         self.bev_h, self.bev_w = cfg['bev_dims']
         self.img_h, self.img_w = cfg['img_dims']
         self.n_slices = cfg['num_slices']
         self.bev_extents_flat = np.asarray(cfg['bev_extents'], np.float64).reshape(-1)
         self.bp = ops.make_bev_params(cfg, synth.velo_to_cam(r0_rect, tr_velo_to_cam),
                                       self.p2, self.image_wh)
+        # streams: conv stacks of the two nets side by side, per-frame work on its own
+        self.img_ctx = device.Context(ctx.device_id)
+        n_side = min(self.nf, 8) if side_streams is None else int(side_streams)
+        self.sides = [device.Context(ctx.device_id) for _ in range(max(n_side, 1))]
 
         # ---- constants of the configuration, resident on the device ----------------
         boxes = gen.tile_anchors_3d(cfg['area_extents'], cfg['anchor_sizes'],
@@ -46,28 +61,30 @@ class FramePairPipeline(object):
         self.d_anchor_table = ctx.array(self.anchors_all)
         self.d_cells = ctx.array(cells)
 
-        # ---- extractors (both frames of the pair are one batch) ----------------------
+        # ---- extractors: every frame of the step is one batch ------------------------
         self.bev_net = BevVggPyr(ctx=ctx)
         self.bev_net.load_params(bev_params or synth.pyramid_params(cfg['bev_depth'], 42))
-        self.bev_net._ensure(2, self.bev_h, self.bev_w, cfg['bev_depth'])
-        self.img_net = ImgVggPyr(ctx=ctx)
+        self.bev_net._ensure(self.nf, self.bev_h, self.bev_w, cfg['bev_depth'])
+        self.img_net = ImgVggPyr(ctx=self.img_ctx)
         self.img_net.load_params(img_params or synth.pyramid_params(cfg['img_depth'], 142))
-        self.img_net._ensure(2, self.img_h, self.img_w, 4)
+        self.img_net._ensure(self.nf, self.img_h, self.img_w, 4)
         p, s = self.bev_net.input_view()
         self.d_bev_in = [ctx.wrap(p + 4 * s * f, (self.bev_h, self.bev_w, cfg['bev_depth']))
-                         for f in range(2)]
+                         for f in range(self.nf)]
         p, s = self.img_net.input_view()
-        self.d_img_in = [ctx.wrap(p + 4 * s * f, (self.img_h, self.img_w, 4)) for f in range(2)]
+        self.d_img_in = [ctx.wrap(p + 4 * s * f, (self.img_h, self.img_w, 4))
+                         for f in range(self.nf)]
 
-        # ---- per-pair work buffers -----------------------------------------------------
+        # ---- work buffers ----------------------------------------------------------------
         f32, i32 = np.float32, np.int32
         N, P = self.n_all, self.P
-        self.d_bev_feat = ctx.empty((2, self.bev_h, self.bev_w, 32), f32)
-        self.d_bev_bneck = ctx.empty((2, self.bev_h, self.bev_w, 1), f32)
-        self.d_img_feat = ctx.empty((2, self.img_h, self.img_w, 32), f32)
-        self.d_img_bneck = ctx.empty((2, self.img_h, self.img_w, 1), f32)
-        self.fr = []
-        for f in range(2):
+        self.feat = [dict(
+            bev_feat=ctx.empty((self.nf, self.bev_h, self.bev_w, 32), f32),
+            bev_bneck=ctx.empty((self.nf, self.bev_h, self.bev_w, 1), f32),
+            img_feat=ctx.empty((self.nf, self.img_h, self.img_w, 32), f32),
+            img_bneck=ctx.empty((self.nf, self.img_h, self.img_w, 1), f32)) for _ in range(2)]
+        self.fr2 = [[], []]
+        for f in range(2 * self.nf):
             b = dict(
                 occ=ctx.empty((self.nz, (self.nx + 31) // 32), np.uint32),
                 keep=ctx.empty((N,), i32), count=ctx.zeros((1,), i32),
@@ -83,89 +100,137 @@ class FramePairPipeline(object):
                 boxes_3d=ctx.empty((P, 7), f32), pred_anchors=ctx.empty((P, 6), f32),
                 nms2_boxes=ctx.empty((P, 4), f32), nms2_scores=ctx.empty((P,), f32),
                 det_idx=ctx.empty((MAX_DET,), i32), det_count=ctx.zeros((1,), i32))
-            self.fr.append(b)
-        # detection records of the pair: what the all-gather ships
-        self.d_records = ctx.empty((2, MAX_DET, REC_COLS), f32)
-        self.d_rec_counts = ctx.zeros((2,), i32)
-        self.last_anchor_counts = [0, 0]
+            self.fr2[f // self.nf].append(b)
+        self.fr = self.fr2[0]          # buffers of the most recently finished step
+        self.step_idx = 0
+        self.pending = None            # step whose tail has not been enqueued yet
+        # detection records of the step: what the all-gather ships
+        self.d_records = ctx.empty((self.pairs, 2, MAX_DET, REC_COLS), f32)
+        self.d_rec_counts = ctx.zeros((self.pairs, 2), i32)
+        self.last_anchor_counts = [0] * self.nf
+        ctx.sync()
 
     def use_record_buffers(self, rec_ptr, cnt_ptr):
         """Write detection records into caller-owned device memory (e.g. the
         torch tensor handed to torch.distributed.all_gather)."""
-        self.d_records = self.ctx.wrap(rec_ptr, (2, MAX_DET, REC_COLS), np.float32)
-        self.d_rec_counts = self.ctx.wrap(cnt_ptr, (2,), np.int32)
+        self.d_records = self.ctx.wrap(rec_ptr, (self.pairs, 2, MAX_DET, REC_COLS), np.float32)
+        self.d_rec_counts = self.ctx.wrap(cnt_ptr, (self.pairs, 2), np.int32)
 
     # ------------------------------------------------------------------------------------
     def run(self, d_points, n_points, d_images, heads):
-        """d_points[f]: (n,4) float32 velodyne xyzi; d_images[f]: (H,W,3) uint8;
-        heads[f]: dict of device arrays rpn_logits (N,2), rpn_offsets (N,6),
-        cls_logits (P,2), offsets_4c (P,10).  All asynchronous on ctx's stream."""
-        ctx, cfg = self.ctx, self.cfg
+        """Enqueue one step.  Lists of length 2 * pairs_per_step, frame order
+        [pair0 f0, pair0 f1, pair1 f0, ...]: d_points[f] (n,4) float32 velodyne xyzi;
+        d_images[f] (H,W,3) uint8; heads[f] dict of device arrays rpn_logits (N,2),
+        rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10).
+        Returns the kept-anchor counts of this step.  The detections of the PREVIOUS
+        step are complete on the main stream when this returns; call finish() after the
+        last step (run(); finish() is the unpipelined form)."""
+        main, nf = self.ctx, self.nf
         mean = (ImgVggPyr._R_MEAN, ImgVggPyr._G_MEAN, ImgVggPyr._B_MEAN)
-        # -- a0-a7: data side of the reference's create_feed_dict ------------------------
-        for f in range(2):
-            b = self.fr[f]
-            ops.bev_slices(ctx, d_points[f], n_points[f], self.bp, self.d_bev_in[f], b['occ'])
-            ops.anchor_filter(ctx, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
+        ns = len(self.sides)
+        cur = self.step_idx & 1
+        fr, feat = self.fr2[cur], self.feat[cur]
+        # -- a0-a7: data side of the reference's create_feed_dict, one frame per stream.
+        #    (ordered behind the previous step's convs by the waits enqueued below)
+        for f in range(nf):
+            c, b = self.sides[f % ns], fr[f]
+            ops.bev_slices(c, d_points[f], n_points[f], self.bp, self.d_bev_in[f], b['occ'])
+            ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
                               b['keep'], b['count'])
-            ops.fetch_i32_begin(ctx, b['count'], 1, f)
-            ops.project_anchors_f64(ctx, self.d_anchor_table, b['keep'], self.n_all, b['count'],
+            ops.fetch_i32_begin(c, b['count'], 1, f // ns)
+            ops.project_anchors_f64(c, self.d_anchor_table, b['keep'], self.n_all, b['count'],
                                     self.bev_extents_flat, self.p2, self.image_wh,
                                     b['bev_norm'], b['img_norm'], b['anchors'])
-            ops.img_preprocess(ctx, d_images[f], (self.image_wh[1], self.image_wh[0]),
+            ops.img_preprocess(c, d_images[f], (self.image_wh[1], self.image_wh[0]),
                                (self.img_h, self.img_w), 4, mean, self.d_img_in[f])
-        # -- a8-a10: conv stacks, both frames per launch ----------------------------------
-        self.bev_net.forward_device(None, self.d_bev_feat, self.d_bev_bneck)
-        self.img_net.forward_device(None, self.d_img_feat, self.d_img_bneck)
-        # kept-anchor counts arrived long ago; the convs are still running
-        counts = [ops.fetch_i32_end(ctx, f, 1)[0] for f in range(2)]
+        for s in self.sides:
+            main.wait_for(s)
+            self.img_ctx.wait_for(s)
+        # -- a8-a10: conv stacks, all frames per launch, the two nets side by side --------
+        self.bev_net.forward_device(None, feat['bev_feat'], feat['bev_bneck'])
+        self.img_net.forward_device(None, feat['img_feat'], feat['img_bneck'])
+        # kept-anchor counts arrive while the convs run
+        counts = [ops.fetch_i32_end(self.sides[f % ns], f // ns, 1)[0] for f in range(nf)]
         self.last_anchor_counts = counts
+        # -- the previous step's tail runs under this step's convs --------------------------
+        if self.pending is not None:
+            self._tail(self.pending)
+        # everything enqueued on the side streams from here on comes after these convs
+        for s in self.sides:
+            s.wait_for(main)
+            s.wait_for(self.img_ctx)
+        for s in self.sides:
+            main.wait_for(s)           # previous step's records are complete on `main`
+        self.pending = dict(cur=cur, heads=heads, counts=counts)
+        self.step_idx += 1
+        return counts
+
+    def finish(self):
+        """Enqueue the tail of the last step; afterwards self.fr / d_records hold it."""
+        if self.pending is not None:
+            self._tail(self.pending)
+            self.pending = None
+        for s in self.sides:
+            self.ctx.wait_for(s)
+
+    def _tail(self, st):
+        """Stages after the extractors for every frame of step `st` (a11-a14)."""
+        cfg, nf = self.cfg, self.nf
+        ns = len(self.sides)
+        fr, feat = self.fr2[st['cur']], self.feat[st['cur']]
+        heads, counts = st['heads'], st['counts']
+        self.fr = fr
         bev_px = self.bev_h * self.bev_w
         img_px = self.img_h * self.img_w
         plane = cfg['ground_plane']
-        for f in range(2):
-            b, h, A = self.fr[f], heads[f], counts[f]
-            bneck_b = self.d_bev_bneck.offset(4 * bev_px * f, (self.bev_h, self.bev_w, 1))
-            bneck_i = self.d_img_bneck.offset(4 * img_px * f, (self.img_h, self.img_w, 1))
-            feat_b = self.d_bev_feat.offset(4 * bev_px * 32 * f, (self.bev_h, self.bev_w, 32))
-            feat_i = self.d_img_feat.offset(4 * img_px * 32 * f, (self.img_h, self.img_w, 32))
+        for f in range(nf):
+            c, b, h, A = self.sides[f % ns], fr[f], heads[f], counts[f]
+            bneck_b = feat['bev_bneck'].offset(4 * bev_px * f, (self.bev_h, self.bev_w, 1))
+            bneck_i = feat['img_bneck'].offset(4 * img_px * f, (self.img_h, self.img_w, 1))
+            feat_b = feat['bev_feat'].offset(4 * bev_px * 32 * f, (self.bev_h, self.bev_w, 32))
+            feat_i = feat['img_feat'].offset(4 * img_px * 32 * f, (self.img_h, self.img_w, 32))
             # -- a11: RPN crops (3x3 on the 1-channel bottlenecks) ------------------------
-            ops.crop_and_resize(ctx, bneck_b, (self.bev_h, self.bev_w, 1), b['bev_norm'], A, None,
+            ops.crop_and_resize(c, bneck_b, (self.bev_h, self.bev_w, 1), b['bev_norm'], A, None,
                                 (3, 3), b['rpn_bev_roi'])
-            ops.crop_and_resize(ctx, bneck_i, (self.img_h, self.img_w, 1), b['img_norm'], A, None,
+            ops.crop_and_resize(c, bneck_i, (self.img_h, self.img_w, 1), b['img_norm'], A, None,
                                 (3, 3), b['rpn_img_roi'])
             # -- a12, a5, a13: decode, project, NMS #1 --------------------------------------
-            ops.offset_to_anchor(ctx, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
-            ops.project_anchors_f32(ctx, b['regressed'], A, None, self.bev_extents_flat, self.p2,
+            ops.offset_to_anchor(c, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
+            ops.project_anchors_f32(c, b['regressed'], A, None, self.bev_extents_flat, self.p2,
                                     self.image_wh, d_bev_norm_tf=b['prop_bev'])
-            ops.softmax_fg(ctx, h['rpn_logits'], A, None, b['scores'])
-            ops.nms(ctx, b['prop_bev'], b['scores'], A, None, self.P,
+            ops.softmax_fg(c, h['rpn_logits'], A, None, b['scores'])
+            ops.nms(c, b['prop_bev'], b['scores'], A, None, self.P,
                     cfg['rpn_nms_iou_thresh'], b['top_idx'], b['top_count'])
-            ops.gather_rows(ctx, b['regressed'], 6, b['top_idx'], self.P, b['top_count'],
+            ops.gather_rows(c, b['regressed'], 6, b['top_idx'], self.P, b['top_count'],
                             b['top_anchors'])
             # -- stage 2: project proposals, 7x7 crops --------------------------------------
-            ops.project_anchors_f32(ctx, b['top_anchors'], self.P, b['top_count'],
+            ops.project_anchors_f32(c, b['top_anchors'], self.P, b['top_count'],
                                     self.bev_extents_flat, self.p2, self.image_wh,
                                     d_bev_norm_tf=b['top_bev'], d_img_norm_tf=b['top_img'])
-            ops.crop_and_resize(ctx, feat_b, (self.bev_h, self.bev_w, 32), b['top_bev'], self.P,
+            ops.crop_and_resize(c, feat_b, (self.bev_h, self.bev_w, 32), b['top_bev'], self.P,
                                 b['top_count'], (7, 7), b['bev_rois'])
-            ops.crop_and_resize(ctx, feat_i, (self.img_h, self.img_w, 32), b['top_img'], self.P,
+            ops.crop_and_resize(c, feat_i, (self.img_h, self.img_w, 32), b['top_img'], self.P,
                                 b['top_count'], (7, 7), b['img_rois'])
             # -- a14, a13: box_4c decode, NMS #2 ---------------------------------------------
-            ops.box_4c_decode(ctx, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
+            ops.box_4c_decode(c, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
                               plane, self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'],
                               b['nms2_boxes'])
-            ops.max_fg_logit(ctx, h['cls_logits'], 2, self.P, b['top_count'], b['nms2_scores'])
-            ops.nms(ctx, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
+            ops.max_fg_logit(c, h['cls_logits'], 2, self.P, b['top_count'], b['nms2_scores'])
+            ops.nms(c, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
                     cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
             ops.pack_detections(
-                ctx, b['boxes_3d'], b['nms2_scores'], b['det_idx'], b['det_count'], MAX_DET,
-                float(f), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
+                c, b['boxes_3d'], b['nms2_scores'], b['det_idx'], b['det_count'], MAX_DET,
+                float(f % 2), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
                 self.d_rec_counts.offset(4 * f, (1,), np.int32))
-        return counts
+
+    def sync(self):
+        self.ctx.sync()
+
+    def flops_per_step(self):
+        return self.bev_net.flops() + self.img_net.flops()
 
     def flops_per_pair(self):
-        return self.bev_net.flops() + self.img_net.flops()
+        return self.flops_per_step() / self.pairs
 
     def close(self):
         self.bev_net.close()

@@ -49,6 +49,11 @@ int dodt_ctx_create(int device_id, dodt_ctx** out);
 int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out);
 int dodt_ctx_destroy(dodt_ctx* ctx);
 int dodt_ctx_sync(dodt_ctx* ctx);
+/* Stream-level join: work enqueued on ctx AFTER this call starts only when
+ * everything enqueued on `other` BEFORE this call has finished (hipEventRecord on
+ * other's stream + hipStreamWaitEvent on ctx's stream; the host does not block).
+ * Lets independent frames run on their own contexts/streams and meet again. */
+int dodt_ctx_wait_for(dodt_ctx* ctx, dodt_ctx* other);
 int dodt_malloc(dodt_ctx* ctx, size_t bytes, void** d_out);
 int dodt_free(dodt_ctx* ctx, void* d_ptr);
 int dodt_memcpy_h2d(dodt_ctx* ctx, void* d_dst, const void* src, size_t bytes);

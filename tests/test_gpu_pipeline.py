@@ -26,6 +26,7 @@ def _run(ctx, pipe, seq, frames, n_points=120000):
     d_imgs = [ctx.array(i) for i in imgs]
     d_heads = [{k: ctx.array(v) for k, v in h.items()} for h in heads]
     counts = pipe.run(d_pts, [len(p) for p in pts], d_imgs, d_heads)
+    pipe.finish()
     ctx.sync()
     return pts, imgs, heads, counts
 
@@ -33,8 +34,8 @@ def _run(ctx, pipe, seq, frames, n_points=120000):
 def test_frame_pair_matches_oracle(setup):
     ctx, pipe = setup
     pts, imgs, heads, counts = _run(ctx, pipe, seq=0, frames=(0, 2))    # tau = 2
-    recs = pipe.d_records.download()
-    rcnt = pipe.d_rec_counts.download()
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    rcnt = pipe.d_rec_counts.download().reshape(-1)
     bev_params = synth.pyramid_params(6, 42)
     img_params = synth.pyramid_params(3, 142)
     for f in range(2):
@@ -69,8 +70,60 @@ def test_frame_pair_matches_oracle(setup):
         if f == 0:
             for name in ('rpn_bev_roi', 'rpn_img_roi', 'bev_rois', 'img_rois'):
                 got = b[name].download()[:len(want[name])]
+                # crops of 16-layer fp32 feature maps: the GPU sums each conv output as
+                # one fmaf chain, the oracle as nine partial GEMMs; the two float32
+                # results drift apart by a few 1e-4 of the map's scale
                 scale = np.abs(want[name]).max() + 1e-12
-                assert np.abs(got - want[name]).max() <= 1e-4 * scale, name
+                assert np.abs(got - want[name]).max() <= 5e-4 * scale, name
+
+
+def test_two_pairs_per_step_match_single_pair_steps(setup):
+    """Batching pairs through the conv stacks and the side streams changes nothing."""
+    ctx, pipe1 = setup
+    pipe2 = FramePairPipeline(ctx, C, rpn_nms_size=1024, pairs_per_step=2)
+    frames = [(3, 0), (3, 2), (5, 1), (5, 3)]
+    pts = [synth.lidar_frame(s, f) for s, f in frames]
+    imgs = [synth.image_frame(s, f) for s, f in frames]
+    heads = [synth.head_outputs(s, f, pipe2.n_all, pipe2.P) for s, f in frames]
+    d_pts = [ctx.array(p) for p in pts]
+    d_imgs = [ctx.array(i) for i in imgs]
+    d_heads = [{k: ctx.array(v) for k, v in h.items()} for h in heads]
+    pipe2.run(d_pts, [len(p) for p in pts], d_imgs, d_heads)
+    pipe2.finish()
+    ctx.sync()
+    both = pipe2.d_records.download()
+    for pair in range(2):
+        sl = slice(2 * pair, 2 * pair + 2)
+        pipe1.run(d_pts[sl], [len(p) for p in pts[sl]], d_imgs[sl], d_heads[sl])
+        pipe1.finish()
+        ctx.sync()
+        assert np.array_equal(pipe1.d_records.download()[0], both[pair])
+        for f in range(2):
+            a, b = pipe1.fr[f], pipe2.fr[2 * pair + f]
+            assert np.array_equal(a['bev_rois'].download(), b['bev_rois'].download())
+            assert np.array_equal(a['img_rois'].download(), b['img_rois'].download())
+    pipe2.close()
+
+
+def test_pipelined_steps_match_unpipelined(setup):
+    """run(); run(); finish() (tail of step k under the convs of step k+1) gives the
+    same detections as run(); finish() per step."""
+    ctx, pipe = setup
+    a = _run(ctx, pipe, seq=6, frames=(0, 2))
+    ra = pipe.d_records.download().copy()
+    b = _run(ctx, pipe, seq=7, frames=(1, 3))
+    rb = pipe.d_records.download().copy()
+
+    def dev(pts, imgs, heads):
+        return ([ctx.array(p) for p in pts], [len(p) for p in pts], [ctx.array(i) for i in imgs],
+                [{k: ctx.array(v) for k, v in h.items()} for h in heads])
+    pipe.run(*dev(a[0], a[1], a[2]))
+    pipe.run(*dev(b[0], b[1], b[2]))
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), ra)       # step 0 is complete
+    pipe.finish()
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), rb)
 
 
 def test_pair_is_repeatable_and_independent(setup):
