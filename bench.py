@@ -29,7 +29,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--points', type=int, default=120000)
     ap.add_argument('--proposals', type=int, default=1024)
-    ap.add_argument('--pairs-per-step', type=int, default=4,
+    ap.add_argument('--pairs-per-step', type=int, default=1,
                     help='independent frame pairs carried by one step on each GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -83,7 +83,7 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    from dodt_amd import config, device, synth
+    from dodt_amd import config, device, sharding, synth
     from dodt_amd.pipeline import FramePairPipeline, MAX_DET, REC_COLS
     cfg = config.PYRAMID_DODT
     stream = torch.cuda.current_stream().cuda_stream
@@ -96,9 +96,9 @@ def main():
     rec = torch.zeros((pps, 2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
     cnt = torch.zeros((pps, 2), dtype=torch.int32, device='cuda')
     pipe.use_record_buffers(rec.data_ptr(), cnt.data_ptr())
-    gathered = torch.zeros((world, pps, 2, MAX_DET, REC_COLS), dtype=torch.float32,
+    gathered = torch.zeros((world * pps, 2, MAX_DET, REC_COLS), dtype=torch.float32,
                            device='cuda')
-    gathered_cnt = torch.zeros((world, pps, 2), dtype=torch.int32, device='cuda')
+    gathered_cnt = torch.zeros((world * pps, 2), dtype=torch.int32, device='cuda')
 
     # a small ring of distinct synthetic batches, resident in HBM before timing starts;
     # every pair of a batch comes from a different sequence (they are independent)
@@ -119,9 +119,8 @@ def main():
     def step(i):
         p = batches[i % n_batches]
         pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rec)
-            dist.all_gather_into_tensor(gathered_cnt, cnt)
+        if world > 1:     # records of the previous step are complete on this stream
+            sharding.all_gather_records(dist, rec, cnt, gathered, gathered_cnt)
 
     def barrier():
         if world > 1:
@@ -139,8 +138,7 @@ def main():
         step(i)
     pipe.finish()
     if world > 1:
-        dist.all_gather_into_tensor(gathered, rec)
-        dist.all_gather_into_tensor(gathered_cnt, cnt)
+        sharding.all_gather_records(dist, rec, cnt, gathered, gathered_cnt)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -168,7 +166,10 @@ def main():
     roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=None,
                     kernel='conv3x3_mfma_kernel (30 launches per step) + 2 first-layer launches',
-                    launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2))
+                    launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
+                    launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),
+                    measured='HIP events, each net alone on its stream, %d reps after the '
+                             'timed region' % reps)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
