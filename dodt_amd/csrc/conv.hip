@@ -107,7 +107,8 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
         if (v.deconv != deconv || v.small_cin != small || Cout % v.BN != 0) continue;
-        if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0)) continue;
+        // the chunk pipeline needs >= 4 chunks of 8 channels per work item
+        if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0 || Cin < 32)) continue;
         const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;
         // mild preference for more work per staged byte
         const double cost = padded * (1.0 + 0.04 / v.MTB + 1.0 / v.BN);
@@ -210,6 +211,7 @@ struct dodt_extractor {
     Buffer buf[NBUF];
     std::vector<Layer> layers;
     float* d_bneck_w = nullptr;
+    int* d_counters = nullptr;  // one work-item counter per layer, zeroed every forward
     float bneck_scale = 1.0f, bneck_shift = 0.0f;
     bool bneck_loaded = false;
     double flops = 0.0;
@@ -254,17 +256,29 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
         static const int dbg = getenv("DODT_CONV_DEBUG") ? atoi(getenv("DODT_CONV_DEBUG")) : 0;
         a.debug = dbg;
     }
+    a.counter = ex->d_counters + (&l - ex->layers.data());
+    a.counter_base = ex->d_counters;
     a.n_tiles = l.Cout / v.BN;
     a.n_items = a.tiles_x * a.tiles_y * ex->batch * a.n_tiles;
     // persistent workgroups: as many as stay resident, each walks items with that stride
     int grid_x = a.n_items;
     if (!v.small_cin) {
-        const int resident = ex->ctx->num_cus * v.blocks_per_cu;
+        static const int bpc_env = getenv("DODT_CONV_BPC") ? atoi(getenv("DODT_CONV_BPC")) : 0;
+        const int bpc = (bpc_env > 0 && bpc_env < v.blocks_per_cu) ? bpc_env : v.blocks_per_cu;
+        const int resident = ex->ctx->num_cus * bpc;
         if (grid_x > resident) grid_x = resident;
     }
     dim3 grid(grid_x, 1);
     v.launch(a, grid, ex->ctx->stream);
     DODT_LAUNCH_CHECK();
+    if (a.debug & 8) {   // diagnostic: print the in-kernel clock of this launch
+        unsigned long long h[2] = {0, 0};
+        (void)hipStreamSynchronize(ex->ctx->stream);
+        (void)hipMemcpy(h, ex->d_counters + 32, sizeof(h), hipMemcpyDeviceToHost);
+        if (h[1])
+            fprintf(stderr, "[dodt] %-16s wg0: %.1f us, shader clock %.3f GHz\n", l.name.c_str(),
+                    h[1] / 100.0, (double)h[0] / h[1] * 0.1);
+    }
     return DODT_OK;
 }
 
@@ -319,6 +333,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
             return DODT_ERR_HIP;
         }
     }
+    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 64 * sizeof(int)));
     // the pad rows of X0 stay zero for the life of the extractor
     DODT_HIP_CHECK(hipMemsetAsync(ex->buf[X0].ptr, 0,
                                   ex->buf[X0].frame_floats() * batch * sizeof(float), ctx->stream));
@@ -379,6 +394,7 @@ int dodt_extractor_destroy(dodt_extractor* ex) {
         if (l.d_shift) (void)hipFree(l.d_shift);
     }
     if (ex->d_bneck_w) (void)hipFree(ex->d_bneck_w);
+    if (ex->d_counters) (void)hipFree(ex->d_counters);
     delete ex;
     return DODT_OK;
 }
@@ -475,6 +491,7 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
                            (long long)x0.frame_floats() / 4, ex->batch);
         DODT_LAUNCH_CHECK();
     }
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 64 * sizeof(int), s));
     int rc;
     auto L = [&](const char* n) -> const Layer& { return ex->layers[find_layer(ex, n)]; };
 #define RUN(name)                                           \

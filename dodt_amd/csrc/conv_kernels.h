@@ -62,6 +62,8 @@ struct ConvArgs {
     int relu;
     int out_y0;    // conv only: rows < out_y0 are dropped, row y lands at y - out_y0
     int out_nhwc;  // 1: NHWC output (last layer), 0: CB8
+    int* counter;  // work-item counter of this launch (zeroed by the host beforehand)
+    int* counter_base;  // start of the counter block (words 32.. are diagnostics)
     int debug;     // ablation switches for tools/ (0 in production): 1 = no epilogue
                    // stores, 2 = no global loads in the K loop, 4 = no MFMAs
 };
@@ -80,7 +82,7 @@ struct ConvCfg {
     static constexpr int kPatchFloats = PH * PW * kPixStride;
     static constexpr int kWFloats = 9 * kCK * BN;
     static constexpr int kBufFloats = kPatchFloats + kWFloats;  // one chunk: patch | weights
-    static constexpr int kLdsBytes = 2 * kBufFloats * 4;         // double buffered
+    static constexpr int kLdsBytes = 2 * kBufFloats * 4 + 16;    // double buffered + control
     static constexpr int kPatchItems = PH * PW * 2;       // float4 per chunk
     static constexpr int kWItems = kWFloats / 4;          // float4 per chunk
     static constexpr int NP = (kPatchItems + 255) / 256;  // per-thread prefetch regs
@@ -138,10 +140,13 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int MT = Cfg::MT, NT = Cfg::NT, NP = Cfg::NP, NW = Cfg::NW;
     constexpr int NACC = DECONV ? 4 : MT * NT;
     constexpr int PS = kPixStride;
+    constexpr int NSLOT = NP + NW;            // staging registers (float4) per thread
+    constexpr int SPT = (NSLOT + 8) / 9;      // staging slots handled per tap
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem;                      // buffer b: [PH*PW][12] at + b * kBufFloats
     float* sW = smem + Cfg::kPatchFloats;  //           [9][2][BN][4] behind it
+    int* s_ctrl = reinterpret_cast<int*>(smem + 2 * Cfg::kBufFloats);  // [0] next work item
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -152,10 +157,9 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     const int tiles = a.tiles_x * a.tiles_y;
     const int items_per_frame = tiles * a.n_tiles;
 
-    // Persistent workgroup: work item = (frame, n-tile, spatial tile), walked with
-    // stride gridDim.x.  The loads of the next item's first chunk are issued during
-    // the last chunk of the current one and the epilogue's stores drain under the next
-    // item's MFMAs, so the matrix pipe never waits for a workgroup to start or end.
+    // Persistent workgroup.  Work item = (frame, n-tile, spatial tile); the first item is
+    // blockIdx.x, further ones come from an atomic counter (a workgroup that starts late
+    // because another stream holds its CU simply takes fewer items).
     struct Item { int frame, ntile, ty0, tx0; };
     auto decode = [&](int it) {
         Item r;
@@ -168,18 +172,16 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         return r;
     };
 
-    // Per-thread staging slots: patch slot k = item (tid + 256 k) -> (pixel p, half g).
-    // Loads are unconditional (halo / surplus slots read a valid dummy address and are
-    // zeroed or skipped at LDS-write time): a load under a branch would make hipcc wait
-    // for it on the spot.  Slot geometry is recomputed where needed (a few VALU ops)
-    // rather than kept in registers across the whole kernel.
+    // Staging slot k < NP: patch float4 (tid + 256 k) -> (pixel p, half g); slot NP + k:
+    // weight float4 (tid + 256 k).  Loads are unconditional (halo / surplus slots read a
+    // valid dummy address and are zeroed or skipped at LDS-write time): a load under a
+    // branch would make hipcc wait for it on the spot.
     int p_glb[NP];        // float offset inside a plane (0 when padded), current load item
-    unsigned p_ok = 0;    // bit k: slot k of the data now in pre_p is real (else zero pad)
-    unsigned p_ok_next = 0;
+    unsigned ok_issue = 0;  // zero-pad mask of the item whose loads are being issued
     const float* in_item = a.in;  // plane 0 of the load item's input
     const f32x4* w_item = reinterpret_cast<const f32x4*>(a.w);
     auto setup_loads = [&](const Item& it) {
-        p_ok_next = 0;
+        ok_issue = 0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int t = tid + k * 256;
@@ -188,36 +190,37 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             const int gy = it.ty0 - 1 + py, gx = it.tx0 - 1 + px;
             const bool ok = t < Cfg::kPatchItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             p_glb[k] = ok ? (gy * a.W + gx) * 8 + g * 4 : 0;
-            p_ok_next |= (ok ? 1u : 0u) << k;
+            ok_issue |= (ok ? 1u : 0u) << k;
         }
         in_item = a.in + (size_t)it.frame * a.in_frame_stride +
                   (size_t)(a.in_coff >> 3) * in_plane;
         w_item = reinterpret_cast<const f32x4*>(a.w + (size_t)it.ntile * nchunks * Cfg::kWFloats);
     };
-    f32x4 pre_p[NP], pre_w[NW];
-#define DODT_ISSUE_LOADS(CH)                                                                  \
+    f32x4 pre[NSLOT];
+    // load staging slot J of chunk CH of the load item into its register
+#define DODT_LOAD_SLOT(J, CH)                                                                 \
     {                                                                                         \
-        const float* plane_ = in_item + (size_t)(CH) * in_plane;                              \
-        _Pragma("unroll") for (int k = 0; k < NP; ++k)                                        \
-            pre_p[k] = *reinterpret_cast<const f32x4*>(plane_ + p_glb[k]);                    \
-        _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                      \
-            const int t = tid + k * 256;                                                      \
-            pre_w[k] = w_item[(size_t)(CH) * Cfg::kWItems + min(t, Cfg::kWItems - 1)];        \
+        if constexpr ((J) < NP) {                                                             \
+            pre[J] = *reinterpret_cast<const f32x4*>(in_item + (size_t)(CH) * in_plane +      \
+                                                     p_glb[(J) < NP ? (J) : 0]);              \
+        } else if constexpr ((J) < NSLOT) {                                                   \
+            const int t_ = tid + ((J) - NP) * 256;                                            \
+            pre[J] = w_item[(size_t)(CH) * Cfg::kWItems + min(t_, Cfg::kWItems - 1)];         \
         }                                                                                     \
     }
-#define DODT_WRITE_LDS(BUF)                                                                   \
+    // write staging slot J (data of the chunk after the one being computed) to buffer BUF
+#define DODT_STORE_SLOT(J, BUF, OKMASK)                                                       \
     {                                                                                         \
-        float* dP_ = sP + (BUF) * Cfg::kBufFloats;                                            \
-        float* dW_ = sW + (BUF) * Cfg::kBufFloats;                                            \
-        _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                      \
-            const int t = tid + k * 256;                                                      \
-            if (t < Cfg::kPatchItems)                                                         \
-                *reinterpret_cast<f32x4*>(dP_ + (t >> 1) * PS + (t & 1) * 4) =                \
-                    ((p_ok >> k) & 1u) ? pre_p[k] : f32x4{0.f, 0.f, 0.f, 0.f};                \
-        }                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                      \
-            const int t = tid + k * 256;                                                      \
-            if (t < Cfg::kWItems) reinterpret_cast<f32x4*>(dW_)[t] = pre_w[k];                \
+        if constexpr ((J) < NP) {                                                             \
+            const int t_ = tid + (J) * 256;                                                   \
+            if (t_ < Cfg::kPatchItems)                                                        \
+                *reinterpret_cast<f32x4*>(sP + (BUF) * Cfg::kBufFloats + (t_ >> 1) * PS +     \
+                                          (t_ & 1) * 4) =                                     \
+                    (((OKMASK) >> (J)) & 1u) ? pre[J] : f32x4{0.f, 0.f, 0.f, 0.f};            \
+        } else if constexpr ((J) < NSLOT) {                                                   \
+            const int t_ = tid + ((J) - NP) * 256;                                            \
+            if (t_ < Cfg::kWItems)                                                            \
+                reinterpret_cast<f32x4*>(sW + (BUF) * Cfg::kBufFloats)[t_] = pre[J];          \
         }                                                                                     \
     }
 
@@ -227,37 +230,55 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     const int w_base = (lh * BN + wn * NT * 32 + li) * 4;
 
     // ---- flat pipeline over (item, chunk) steps --------------------------------------------
-    //   step k:  [write chunk k+1 (in registers since step k-1) to LDS buffer (k+1)&1]
-    //            [issue the global loads of chunk k+2]  [MFMAs of chunk k from buffer k&1]
-    //            [epilogue if chunk k ends an item]  [ONE barrier]
+    //   step k:  MFMAs of chunk k from LDS buffer k&1; in their shadow, spread over the nine
+    //            taps: chunk k+1 (in registers since step k-1) is written to buffer (k+1)&1
+    //            and the global loads of chunk k+2 are issued into the freed registers;
+    //            epilogue if chunk k ends an item; ONE barrier.
     // The chunk sequence runs across item boundaries, so neither the first loads of an
     // item nor its stores ever leave the matrix pipe idle.
-    if ((int)blockIdx.x >= a.n_items) return;  // uniform per workgroup
-    int load_item = blockIdx.x, load_ch = 0;   // next chunk to issue loads for
     int comp_item = blockIdx.x, comp_ch = 0;   // chunk the MFMAs work on
-    bool regs_full = false;
-    unsigned regs_ok = 0;                       // zero-pad mask of the data in pre_p
+    if (comp_item >= a.n_items) return;        // uniform per workgroup
+    // diagnostic build switch (debug & 8): shader clock of workgroup 0, written to words
+    // that nothing else reads (counter[32..35]); see MI355X_MICROARCH 'DVFS give-back'
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if ((a.debug & 8) && blockIdx.x == 0 && tid == 0) {
+        dbg_t0 = __builtin_amdgcn_s_memtime();
+        dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    int load_item = comp_item, load_ch = 0;    // chunk whose loads are issued next
+    int next_item = a.n_items;                 // successor of comp_item (from the counter);
+                                               // fetched during an item's first step and not
+                                               // needed before its chunk nchunks-2 (host
+                                               // guarantees nchunks >= 4)
     setup_loads(decode(load_item));
+    unsigned ok_regs = ok_issue;               // mask of the data sitting in pre[]
+    // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
 #define DODT_ADVANCE_LOAD()                                                                   \
     {                                                                                         \
         if (++load_ch == nchunks) {                                                           \
             load_ch = 0;                                                                      \
-            load_item += gridDim.x;                                                           \
+            load_item = next_item;                                                            \
             if (load_item < a.n_items) setup_loads(decode(load_item));                        \
         }                                                                                     \
     }
-    DODT_ISSUE_LOADS(0)
-    regs_ok = p_ok_next;
-    DODT_ADVANCE_LOAD()
-    p_ok = regs_ok;
-    DODT_WRITE_LDS(0)
-    if (load_item < a.n_items && !(a.debug & 2)) {
-        DODT_ISSUE_LOADS(load_ch)
-        regs_ok = p_ok_next;
-        regs_full = true;
-        DODT_ADVANCE_LOAD()
-    }
+#define DODT_FOR_SLOTS(BODY) \
+    { BODY(0) BODY(1) BODY(2) BODY(3) BODY(4) BODY(5) BODY(6) BODY(7) BODY(8) BODY(9) BODY(10) \
+      BODY(11) BODY(12) BODY(13) BODY(14) BODY(15) BODY(16) BODY(17) }
+    static_assert(NSLOT <= 18, "raise DODT_FOR_SLOTS");
+#define DODT_PRO_LOAD(J) DODT_LOAD_SLOT(J, 0)
+#define DODT_PRO_STORE(J) DODT_STORE_SLOT(J, 0, ok_regs)
+    DODT_FOR_SLOTS(DODT_PRO_LOAD)
+    DODT_FOR_SLOTS(DODT_PRO_STORE)
     __syncthreads();
+    DODT_ADVANCE_LOAD()
+    ok_regs = ok_issue;
+    {
+        const int ch_ = load_ch;
+#define DODT_PRO_LOAD1(J) DODT_LOAD_SLOT(J, ch_)
+        DODT_FOR_SLOTS(DODT_PRO_LOAD1)   // harmless re-read of a valid address if no chunk is left
+    }
+    bool more_loads = load_item < a.n_items;   // pre[] holds a real chunk
+    if (more_loads) DODT_ADVANCE_LOAD()
 
     f32x16 acc[NACC];
 #pragma unroll
@@ -269,19 +290,20 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     while (comp_item < a.n_items) {
         const float* bP = sP + buf * Cfg::kBufFloats;
         const float* bW = sW + buf * Cfg::kBufFloats;
-        if (regs_full) {
-            p_ok = regs_ok;
-            DODT_WRITE_LDS(buf ^ 1)   // waits for loads issued one whole step ago
-            regs_full = false;
-        }
-        if (load_item < a.n_items && !(a.debug & 2)) {
-            DODT_ISSUE_LOADS(load_ch)  // in flight during the MFMAs below
-            regs_ok = p_ok_next;
-            regs_full = true;
-            DODT_ADVANCE_LOAD()
-        }
+        // staging plan of this step: write the registers (chunk k+1) to buffer buf^1, then
+        // refill them with chunk k+2 = (load_item, load_ch) -- all unconditional
+        const unsigned ok_store = ok_regs;
+        const int ld_ch = load_ch;
+        const bool more = load_item < a.n_items;   // a real chunk is left to load
+        const bool issue = !(a.debug & 2);         // production: always (a surplus load
+                                                   // re-reads a valid address, no branch)
+        if (comp_ch == 0 && tid == 0)   // fetch the successor of the item being computed
+            s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+
         if (a.debug & 4) {
-            // ablation: no MFMAs
+            // ablation: no MFMAs (staging still runs)
+#define DODT_ABL(J) DODT_STORE_SLOT(J, buf ^ 1, ok_store) DODT_LOAD_SLOT(J, ld_ch)
+            DODT_FOR_SLOTS(DODT_ABL)
         } else if constexpr (!DECONV) {
             f32x4 xf[2][MT], wf[2][NT];
 #pragma unroll
@@ -291,33 +313,45 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 wf[0][nt] = *reinterpret_cast<const f32x4*>(bW + w_base + nt * 128);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int cb = tap & 1, nb = cb ^ 1;
-                if (tap + 1 < 9) {
-                    const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        xf[nb][mt] = *reinterpret_cast<const f32x4*>(
-                            bP + x_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        wf[nb][nt] = *reinterpret_cast<const f32x4*>(
-                            bW + w_base + (tap + 1) * 2 * BN * 4 + nt * 128);
-                }
-                // the next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc would
-                // otherwise sink them below to save registers and expose their latency)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt * NT + nt] =
-                                mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);
-                __builtin_amdgcn_sched_barrier(0);
+#define DODT_TAP(TAP)                                                                         \
+            {                                                                                 \
+                constexpr int cb = (TAP) & 1, nb = cb ^ 1;                                    \
+                if constexpr ((TAP) + 1 < 9) {                                                \
+                    constexpr int ky = ((TAP) + 1) / 3, kx = ((TAP) + 1) % 3;                 \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
+                        xf[nb][mt] = *reinterpret_cast<const f32x4*>(                         \
+                            bP + x_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);      \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                        wf[nb][nt] = *reinterpret_cast<const f32x4*>(                         \
+                            bW + w_base + ((TAP) + 1) * 2 * BN * 4 + nt * 128);               \
+                }                                                                             \
+                /* the next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc would */       \
+                /* otherwise sink them below to save registers and expose their latency) */   \
+                __builtin_amdgcn_sched_barrier(0);                                            \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                 \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
+                            acc[mt * NT + nt] =                                               \
+                                mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);      \
+                /* staging in the shadow of the MFMAs just issued */                          \
+                DODT_STAGE_TAP(TAP)                                                           \
+                _Pragma("unroll") for (int s = 2; s < 4; ++s)                                 \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
+                            acc[mt * NT + nt] =                                               \
+                                mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);      \
+                __builtin_amdgcn_sched_barrier(0);                                            \
             }
+#define DODT_STAGE_ONE(J)                                                                     \
+            DODT_STORE_SLOT(J, buf ^ 1, ok_store) if (issue) DODT_LOAD_SLOT(J, ld_ch)
+#define DODT_STAGE_TAP(TAP)                                                                   \
+            {                                                                                 \
+                if constexpr (SPT >= 1) { DODT_STAGE_ONE((TAP) * SPT + 0) }                   \
+                if constexpr (SPT >= 2) { DODT_STAGE_ONE((TAP) * SPT + 1) }                   \
+            }
+            static_assert(SPT <= 2, "more than two staging slots per tap");
+            DODT_TAP(0) DODT_TAP(1) DODT_TAP(2) DODT_TAP(3) DODT_TAP(4)
+            DODT_TAP(5) DODT_TAP(6) DODT_TAP(7) DODT_TAP(8)
         } else {
             // patch origin is (ty0-1, tx0-1): in[i][j] sits at patch (r+1, c+1)
             const float* pa = bP + x_base;
@@ -329,21 +363,33 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
                 bw[tap] = *reinterpret_cast<const f32x4*>(bW + w_base + tap * 2 * BN * 4);
+            __builtin_amdgcn_sched_barrier(0);
             // taps ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj] * w[ky][kx]
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0] = mfma32(bw[0][s], a00[s], acc[0]);
-                acc[1] = mfma32(bw[1][s], a00[s], acc[1]);
-                acc[2] = mfma32(bw[3][s], a00[s], acc[2]);
-                acc[3] = mfma32(bw[4][s], a00[s], acc[3]);
-                acc[0] = mfma32(bw[6][s], a10[s], acc[0]);
-                acc[1] = mfma32(bw[7][s], a10[s], acc[1]);
-                acc[2] = mfma32(bw[5][s], a01[s], acc[2]);
-                acc[0] = mfma32(bw[2][s], a01[s], acc[0]);
-                acc[0] = mfma32(bw[8][s], a11[s], acc[0]);
-            }
+#define DODT_DECONV_S(S, STAGE_A, STAGE_B)                                                    \
+            acc[0] = mfma32(bw[0][S], a00[S], acc[0]);                                        \
+            acc[1] = mfma32(bw[1][S], a00[S], acc[1]);                                        \
+            acc[2] = mfma32(bw[3][S], a00[S], acc[2]);                                        \
+            acc[3] = mfma32(bw[4][S], a00[S], acc[3]);                                        \
+            STAGE_A                                                                           \
+            acc[0] = mfma32(bw[6][S], a10[S], acc[0]);                                        \
+            acc[1] = mfma32(bw[7][S], a10[S], acc[1]);                                        \
+            acc[2] = mfma32(bw[5][S], a01[S], acc[2]);                                        \
+            STAGE_B                                                                           \
+            acc[0] = mfma32(bw[2][S], a01[S], acc[0]);                                        \
+            acc[0] = mfma32(bw[8][S], a11[S], acc[0]);
+            DODT_DECONV_S(0, DODT_STAGE_TAP(0), DODT_STAGE_TAP(1))
+            DODT_DECONV_S(1, DODT_STAGE_TAP(2), DODT_STAGE_TAP(3))
+            DODT_DECONV_S(2, DODT_STAGE_TAP(4), DODT_STAGE_TAP(5))
+            DODT_DECONV_S(3, DODT_STAGE_TAP(6), DODT_STAGE_TAP(7))
+            DODT_STAGE_TAP(8)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (++comp_ch == nchunks) {
+        if (more) {
+            ok_regs = ok_issue;       // pre[] now holds (load_item, ld_ch)
+            DODT_ADVANCE_LOAD()       // uses next_item read after an earlier barrier
+        }
+        const bool item_done = (comp_ch + 1 == nchunks);
+        if (item_done) {
             // ---- epilogue: the stores drain under the next item's MFMAs ---------------
             const Item cur = decode(comp_item);
             float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
@@ -376,15 +422,32 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             for (int k = 0; k < NACC; ++k)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-            comp_ch = 0;
-            comp_item += gridDim.x;
         }
-        __syncthreads();  // buffer buf^1 is complete, buffer buf is free
+        __syncthreads();  // buffer buf^1 is complete, buffer buf is free, s_ctrl is visible
         buf ^= 1;
+        if (comp_ch == 0) next_item = s_ctrl[0];   // fetched at the top of this step
+        if (item_done) {
+            comp_ch = 0;
+            comp_item = next_item;
+        } else {
+            ++comp_ch;
+        }
     }
-#undef DODT_ISSUE_LOADS
-#undef DODT_WRITE_LDS
+    if ((a.debug & 8) && blockIdx.x == 0 && tid == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.counter + 32 - (a.counter - a.counter_base));
+        o[0] = t1 - dbg_t0;
+        o[1] = r1 - dbg_r0;
+    }
+#undef DODT_LOAD_SLOT
+#undef DODT_STORE_SLOT
 #undef DODT_ADVANCE_LOAD
+#undef DODT_FOR_SLOTS
+#undef DODT_TAP
+#undef DODT_STAGE_ONE
+#undef DODT_STAGE_TAP
+#undef DODT_DECONV_S
 }
 
 // ---------------------------------------------------------------------------
