@@ -44,6 +44,7 @@ _f = C.c_float
 _d = C.c_double
 _pi32 = C.c_void_p      # device int32*
 _pf = C.c_void_p        # device float*
+_hf = C.c_void_p        # host float*
 
 # name -> (restype, argtypes); every name here is declared in include/dodt_hip.h
 SIGNATURES = {
@@ -86,12 +87,17 @@ SIGNATURES = {
     'dodt_extractor_flops': (_d, [_vp]),
     'dodt_crop_and_resize': (_i, [_vp, _pf, _i, _i, _i, _pf, _i, _pi32, _i, _i,
                                   _pf]),
+    'dodt_correlation': (_i, [_vp, _pf, _pf, _i, _i, _i, _i, _i, _i, _pf]),
+    'dodt_fc_create': (_i, [_vp, _i, _i, _hf, _hf, _i, C.POINTER(_vp)]),
+    'dodt_fc_destroy': (_i, [_vp]),
+    'dodt_fc_forward': (_i, [_vp, _vp, _pf, _pf, _i, _i, _pi32, _pf, _i]),
+    'dodt_fc_flops': (_d, [_vp, _i]),
     'dodt_nms': (_i, [_vp, _pf, _pf, _i, _pi32, _i, _f, _pi32, _pi32]),
     'dodt_offset_to_anchor': (_i, [_vp, _pf, _pf, _i, _pi32, _pf]),
     'dodt_softmax_fg': (_i, [_vp, _pf, _i, _pi32, _pf]),
     'dodt_gather_rows': (_i, [_vp, _pf, _i, _pi32, _i, _pi32, _pf]),
     'dodt_max_fg_logit': (_i, [_vp, _pf, _i, _i, _pi32, _pf]),
-    'dodt_pack_detections': (_i, [_vp, _pf, _pf, _pi32, _pi32, _i, _f, _pf, _pi32]),
+    'dodt_pack_detections': (_i, [_vp, _pf, _pf, _pf, _pi32, _pi32, _i, _f, _pf, _pi32]),
     'dodt_box_4c_decode': (_i, [_vp, _pf, _pf, _i, _pi32, C.POINTER(_f),
                                 C.POINTER(_f), _pf, _pf, _pf]),
 }

@@ -258,8 +258,9 @@ max_fg_logit_kernel(const float* __restrict__ logits, int n_cls, int n,
 
 __global__ void __launch_bounds__(256)
 pack_detections_kernel(const float* __restrict__ boxes_3d, const float* __restrict__ scores,
-                       const int* __restrict__ sel, const int* __restrict__ d_count, int max_det,
-                       float frame_mark, float* __restrict__ rec, int* __restrict__ count_out) {
+                       const float* __restrict__ corr, const int* __restrict__ sel,
+                       const int* __restrict__ d_count, int max_det, float frame_mark,
+                       float* __restrict__ rec, int* __restrict__ count_out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = min(*d_count, max_det);
     if (t == 0) *count_out = cnt;
@@ -271,6 +272,14 @@ pack_detections_kernel(const float* __restrict__ boxes_3d, const float* __restri
         if (col < 7) v = boxes_3d[(size_t)src * 7 + col];
         else if (col == 7) v = scores[src];
         else if (col == 16) v = frame_mark;
+        else if (col >= 9 && corr) {
+            // dt_evaluator.py:1217-1224: the box shifted by (dx, dz, dry) into the next frame
+            const int c = col - 9;
+            v = boxes_3d[(size_t)src * 7 + c];
+            if (c == 0) v += corr[(size_t)src * 3 + 0];
+            else if (c == 2) v += corr[(size_t)src * 3 + 1];
+            else if (c == 6) v += corr[(size_t)src * 3 + 2];
+        }
     }
     rec[t] = v;
 }
@@ -485,13 +494,15 @@ int dodt_max_fg_logit(dodt_ctx* ctx, const float* d_logits, int n_cls, int n, co
 }
 
 int dodt_pack_detections(dodt_ctx* ctx, const float* d_boxes_3d, const float* d_scores,
-                         const int32_t* d_sel, const int32_t* d_count, int max_det,
-                         float frame_mark, float* d_rec_out, int32_t* d_count_out) {
+                         const float* d_corr_offsets, const int32_t* d_sel,
+                         const int32_t* d_count, int max_det, float frame_mark,
+                         float* d_rec_out, int32_t* d_count_out) {
     DODT_REQUIRE(ctx && d_boxes_3d && d_scores && d_sel && d_count && d_rec_out && d_count_out &&
                      max_det > 0,
                  "dodt_pack_detections: bad argument");
     hipLaunchKernelGGL(pack_detections_kernel, dim3(dodt::ceil_div(max_det * 17, 256)), dim3(256),
-                       0, ctx->stream, d_boxes_3d, d_scores, d_sel, d_count, max_det, frame_mark,
+                       0, ctx->stream, d_boxes_3d, d_scores, d_corr_offsets, d_sel, d_count, max_det,
+                       frame_mark,
                        d_rec_out, d_count_out);
     DODT_LAUNCH_CHECK();
     return DODT_OK;

@@ -1,0 +1,272 @@
+// Fully connected layers of the dense heads on the fp32 MFMA of gfx950.
+//
+// Reference call sites: the RPN anchor predictor (avod/core/models/dt_rpn_model.py:445-537:
+// a 3x3 VALID conv = FC 9->256, then 1x1 convs 256->256->{2,6}, slim.conv2d defaults: bias +
+// ReLU, none on the last layer) and the stage-2 heads (avod/core/avod_fc_layers/
+// fusion_fc_layers.py:136-180 early fusion: mean of the BEV and image crops, flatten,
+// three slim.fully_connected 2048 + cls/off/ang outputs; avod/builders/
+// avod_corr_layers_builder.py:120-160 the same on the correlation crops -> 3 offsets).
+//
+// y[M][N] = act(x[M][K] . w[K][N] + b[N]), fp32, v_mfma_f32_32x32x2_f32.
+//   * samples are the MFMA's A operand, weights its B operand: in the 32x32 result a lane
+//     owns one output feature and 16 samples, so a store instruction writes 32 consecutive
+//     features of a sample (128 B).
+//   * weights are pre-blocked on the host as [n-tile][K/8][h][BN][4] (the two MFMA k-lanes
+//     take k = s and s + 4): one ds_read_b128 per operand feeds four MFMAs, like the conv.
+//   * a stage = 32 k; x tile [BM][32 + 4 pad] (conflict-free b128 reads), two LDS buffers,
+//     the next stage's global loads are in registers while the current one computes.
+//   * optional second input: x = (x1 + x2) / 2, the heads' "mean" fusion, folded into the
+//     load of the first layer (tf.reduce_sum over the two crops / 2.0).
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBK = 32;       // k per stage
+constexpr int kXS = kBK + 4;  // LDS floats per x row
+
+struct GemmArgs {
+    const float* x;
+    const float* x2;   // may be NULL
+    const float* w;    // blocked
+    const float* bias; // [Npad]
+    float* y;
+    int M, K, Kp, N, ldx, ldy, relu;
+    const int* d_m;    // may be NULL: rows >= *d_m are skipped
+};
+
+template <int BM, int BN, int WM, int WN, bool XVEC>
+__global__ void __launch_bounds__(256)
+fc_mfma_kernel(const GemmArgs a) {
+    constexpr int MT = BM / 32 / WM, NT = BN / 32 / WN;
+    constexpr int XITEMS = BM * (kBK / 4);   // float4 per stage
+    constexpr int WITEMS = kBK * BN / 4;
+    constexpr int NX = (XITEMS + 255) / 256, NW = (WITEMS + 255) / 256;
+    constexpr int kBuf = BM * kXS + kBK * BN;  // floats per LDS buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM, nt0 = blockIdx.y;
+    const int M = a.d_m ? min(*a.d_m, a.M) : a.M;
+    if (m0 >= M) return;
+    const int nstages = a.Kp / kBK;
+    const f32x4* wblk = reinterpret_cast<const f32x4*>(a.w) + (size_t)nt0 * (a.Kp / 8) * 2 * BN;
+
+    f32x4 px[NX], pw[NW];
+    auto load_stage = [&](int st) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int t = tid + k * 256;
+            const int row = min(t / (kBK / 4), BM - 1), q = t % (kBK / 4);
+            const int m = min(m0 + row, M - 1);          // clamp: surplus rows are never stored
+            const int kk = st * kBK + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (XVEC) {
+                if (kk < a.K) {
+                    v = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + kk);
+                    if (a.x2) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(a.x2 + (size_t)m * a.ldx + kk);
+                        v = (v + u) / 2.0f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < a.K) {
+                        float s = a.x[(size_t)m * a.ldx + kk + e];
+                        if (a.x2) s = (s + a.x2[(size_t)m * a.ldx + kk + e]) / 2.0f;
+                        v[e] = s;
+                    }
+            }
+            px[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int t = min(tid + k * 256, WITEMS - 1);
+            pw[k] = wblk[(size_t)st * WITEMS + t];
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* sX = smem + buf * kBuf;
+        float* sW = sX + BM * kXS;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int t = tid + k * 256;
+            if (t < XITEMS)
+                *reinterpret_cast<f32x4*>(sX + (t / (kBK / 4)) * kXS + (t % (kBK / 4)) * 4) = px[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int t = tid + k * 256;
+            if (t < WITEMS) reinterpret_cast<f32x4*>(sW)[t] = pw[k];
+        }
+    };
+
+    f32x16 acc[MT * NT];
+#pragma unroll
+    for (int k = 0; k < MT * NT; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstages) load_stage(st + 1);   // in flight during the MFMAs
+        const float* sX = smem + buf * kBuf;
+        const float* sW = sX + BM * kXS;
+#pragma unroll
+        for (int q = 0; q < kBK / 8; ++q) {
+            f32x4 xf[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                xf[mt] = *reinterpret_cast<const f32x4*>(
+                    sX + ((wm * MT + mt) * 32 + li) * kXS + q * 8 + lh * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const f32x4*>(
+                    sW + ((q * 2 + lh) * BN + (wn * NT + nt) * 32 + li) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            xf[mt][s], wf[nt][s], acc[mt * NT + nt], 0, 0, 0);
+        }
+        if (st + 1 < nstages) {
+            store_stage(buf ^ 1);   // the other buffer: last read before the previous barrier
+            __syncthreads();
+        }
+    }
+    // epilogue: bias + activation; lane = feature, registers = samples
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt0 * BN + (wn * NT + nt) * 32 + li;
+        const float b = a.bias[n];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M && n < a.N) {
+                    float v = acc[mt * NT + nt][r] + b;
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    a.y[(size_t)m * a.ldy + n] = v;
+                }
+            }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
+    constexpr size_t lds = 2 * (size_t)(BM * kXS + kBK * BN) * sizeof(float);
+    const bool vec = (a.ldx % 4 == 0) && (a.K % 4 == 0);
+    dim3 grid(dodt::ceil_div(a.M, BM), Npad / BN);
+    if (vec) {
+        static bool p = false;
+        if (!p) {
+            DODT_HIP_CHECK(hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&fc_mfma_kernel<BM, BN, WM, WN, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            p = true;
+        }
+        hipLaunchKernelGGL((fc_mfma_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, s, a);
+    } else {
+        static bool p = false;
+        if (!p) {
+            DODT_HIP_CHECK(hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&fc_mfma_kernel<BM, BN, WM, WN, false>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            p = true;
+        }
+        hipLaunchKernelGGL((fc_mfma_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, s, a);
+    }
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+}  // namespace
+
+struct dodt_fc {
+    dodt_ctx* ctx = nullptr;
+    int K = 0, Kp = 0, N = 0, Npad = 0, BN = 0, relu = 0;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+};
+
+extern "C" {
+
+int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int relu,
+                   dodt_fc** out) {
+    DODT_REQUIRE(ctx && w && bias && out, "dodt_fc_create: NULL argument");
+    DODT_REQUIRE(K >= 1 && N >= 1, "dodt_fc_create: bad sizes");
+    dodt_fc* f = new dodt_fc();
+    f->ctx = ctx;
+    f->K = K;
+    f->N = N;
+    f->relu = relu;
+    f->Kp = (int)dodt::align_up((size_t)K, kBK);
+    f->BN = (N >= 128) ? 128 : 32;
+    f->Npad = (int)dodt::align_up((size_t)N, (size_t)f->BN);
+    // blocked weights [n-tile][Kp/8][h][BN][4]; k = 8q + 4h + s
+    std::vector<float> blk((size_t)f->Kp * f->Npad, 0.0f), b(f->Npad, 0.0f);
+    const int K8 = f->Kp / 8;
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) {
+            const int q = k / 8, h = (k % 8) / 4, s = k % 4, nt = n / f->BN, nn = n % f->BN;
+            blk[((((size_t)nt * K8 + q) * 2 + h) * f->BN + nn) * 4 + s] = w[(size_t)k * N + n];
+        }
+    for (int n = 0; n < N; ++n) b[n] = bias[n];
+    hipError_t e1 = hipMalloc(&f->d_w, blk.size() * sizeof(float));
+    hipError_t e2 = hipMalloc(&f->d_b, b.size() * sizeof(float));
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        dodt::set_error("dodt_fc_create: hipMalloc failed");
+        dodt_fc_destroy(f);
+        return DODT_ERR_HIP;
+    }
+    DODT_HIP_CHECK(hipMemcpyAsync(f->d_w, blk.data(), blk.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, ctx->stream));
+    DODT_HIP_CHECK(hipMemcpyAsync(f->d_b, b.data(), b.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, ctx->stream));
+    DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = f;
+    return DODT_OK;
+}
+
+int dodt_fc_destroy(dodt_fc* f) {
+    if (!f) return DODT_OK;
+    if (f->d_w) (void)hipFree(f->d_w);
+    if (f->d_b) (void)hipFree(f->d_b);
+    delete f;
+    return DODT_OK;
+}
+
+int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_x2, int ldx,
+                    int M, const int32_t* d_m, float* d_y, int ldy) {
+    DODT_REQUIRE(f && d_x && d_y, "dodt_fc_forward: NULL argument");
+    DODT_REQUIRE(M >= 0 && ldx >= f->K && ldy >= f->N, "dodt_fc_forward: bad strides");
+    if (M == 0) return DODT_OK;
+    GemmArgs a;
+    a.x = d_x; a.x2 = d_x2; a.w = f->d_w; a.bias = f->d_b; a.y = d_y;
+    a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = ldy; a.relu = f->relu;
+    a.d_m = d_m;
+    hipStream_t s = (ctx ? ctx : f->ctx)->stream;
+    if (f->BN == 128) return launch_fc<64, 128, 2, 2>(s, a, f->Npad);
+    return launch_fc<128, 32, 4, 1>(s, a, f->Npad);
+}
+
+double dodt_fc_flops(const dodt_fc* f, int M) {
+    return f ? 2.0 * M * (double)f->K * f->N : 0.0;
+}
+
+}  // extern "C"

@@ -79,47 +79,60 @@ __global__ void __launch_bounds__(256)
 vox_scatter(const void* __restrict__ pts, const VoxParams P, uint32_t* __restrict__ out,
             uint32_t* __restrict__ occ, uint32_t* __restrict__ list,
             uint32_t* __restrict__ counters, uint32_t list_cap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
+    // Per-workgroup staging of everything that would otherwise hammer ONE global word:
+    // slice member counts and the append cursor of the touched-cell list (18k same-address
+    // atomics per frame cost ~100 us; one atomic per workgroup and counter costs ~nothing).
+    __shared__ uint32_t s_cnt[kMaxSlices];
+    __shared__ uint32_t s_n;                       // entries staged by this workgroup
+    __shared__ uint32_t s_base;                    // their position in the global list
+    __shared__ uint32_t s_items[256 * (kMaxSlices + 1)];
+    const int tid = threadIdx.x;
+    if (tid < kMaxSlices) s_cnt[tid] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+
+    const int i = blockIdx.x * blockDim.x + tid;
     double x, y, z;
-    if (!load_point(pts, P, i, x, y, z)) return;
-    if (!(x > P.ext[0] && x < P.ext[1] && y > P.ext[2] && y < P.ext[3] && z > P.ext[4] &&
-          z < P.ext[5]))
-        return;
-    // (plane + [0,0,0,-off]) . [x,y,z,1] < 0 ; d - off is folded on the host
-    const double dotp = fma(P.c, z, fma(P.b, y, P.a * x));
-    const int xi = (int)floor(x / P.vs) - P.cx_min;
-    const int yb = (int)floor(y / P.vs) - P.cy_min;
-    const int zi = (int)floor(z / P.vs) - P.cz_min;
-    if (xi < 0 || xi >= P.X || zi < 0 || zi >= P.Z || yb < 0 || yb > 126) {
-        atomicOr(&counters[kCntErr], 1u);  // reference: ValueError("Extents are smaller ...")
-        return;
-    }
-    const int C = P.S + 1;
-    const uint32_t base = (uint32_t)(((P.Z - 1 - zi) * P.X + xi) * C);
-    const uint32_t key = ~(((uint32_t)yb << kIdxBits) | (uint32_t)i);
-    for (int s = 0; s < P.S; ++s) {
-        const bool member = ((dotp + P.d_hi[s]) < 0.0) != ((dotp + P.d_lo[s]) < 0.0);
-        if (member) {
-            const uint32_t old = atomicMax(&out[base + s], key);
-            if (old == 0u) {
-                const uint32_t slot = atomicAdd(&counters[kCntList], 1u);
-                if (slot < list_cap) list[slot] = base + s;
+    bool ok = i < P.n && load_point(pts, P, i, x, y, z);
+    ok = ok && (x > P.ext[0] && x < P.ext[1] && y > P.ext[2] && y < P.ext[3] && z > P.ext[4] &&
+                z < P.ext[5]);
+    if (ok) {
+        // (plane + [0,0,0,-off]) . [x,y,z,1] < 0 ; d - off is folded on the host
+        const double dotp = fma(P.c, z, fma(P.b, y, P.a * x));
+        const int xi = (int)floor(x / P.vs) - P.cx_min;
+        const int yb = (int)floor(y / P.vs) - P.cy_min;
+        const int zi = (int)floor(z / P.vs) - P.cz_min;
+        if (xi < 0 || xi >= P.X || zi < 0 || zi >= P.Z || yb < 0 || yb > 126) {
+            atomicOr(&counters[kCntErr], 1u);  // reference: ValueError("Extents are smaller ...")
+        } else {
+            const int C = P.S + 1;
+            const uint32_t base = (uint32_t)(((P.Z - 1 - zi) * P.X + xi) * C);
+            const uint32_t key = ~(((uint32_t)yb << kIdxBits) | (uint32_t)i);
+            for (int s = 0; s < P.S; ++s) {
+                const bool member = ((dotp + P.d_hi[s]) < 0.0) != ((dotp + P.d_lo[s]) < 0.0);
+                if (member) {
+                    const uint32_t old = atomicMax(&out[base + s], key);
+                    if (old == 0u) s_items[atomicAdd(&s_n, 1u)] = base + s;
+                    atomicAdd(&s_cnt[s], 1u);
+                }
             }
-            atomicAdd(&counters[kCntSlice + s], 1u);
+            if (((dotp + P.dens_d_hi) < 0.0) != ((dotp + P.dens_d_lo) < 0.0)) {
+                const uint32_t old = atomicAdd(&out[base + P.S], 1u);
+                if (old == 0u) s_items[atomicAdd(&s_n, 1u)] = base + P.S;
+            }
+            if (occ != nullptr &&
+                (((dotp + P.occ_d_hi) < 0.0) != ((dotp + P.occ_d_lo) < 0.0))) {
+                atomicOr(&occ[zi * P.occ_words_per_row + (xi >> 5)], 1u << (xi & 31));
+            }
         }
     }
-    if (((dotp + P.dens_d_hi) < 0.0) != ((dotp + P.dens_d_lo) < 0.0)) {
-        const uint32_t old = atomicAdd(&out[base + P.S], 1u);
-        if (old == 0u) {
-            const uint32_t slot = atomicAdd(&counters[kCntList], 1u);
-            if (slot < list_cap) list[slot] = base + P.S;
-        }
-    }
-    if (occ != nullptr &&
-        (((dotp + P.occ_d_hi) < 0.0) != ((dotp + P.occ_d_lo) < 0.0))) {
-        atomicOr(&occ[zi * P.occ_words_per_row + (xi >> 5)], 1u << (xi & 31));
-    }
+    __syncthreads();
+    if (tid < P.S && s_cnt[tid]) atomicAdd(&counters[kCntSlice + tid], s_cnt[tid]);
+    if (tid == 0) s_base = s_n ? atomicAdd(&counters[kCntList], s_n) : 0u;
+    __syncthreads();
+    const uint32_t n = s_n, gbase = s_base;
+    for (uint32_t k = tid; k < n; k += 256)
+        if (gbase + k < list_cap) list[gbase + k] = s_items[k];
 }
 
 __global__ void __launch_bounds__(256)

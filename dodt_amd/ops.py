@@ -132,9 +132,10 @@ def max_fg_logit(ctx, d_logits, n_cls, n, d_n, d_scores):
 
 
 def pack_detections(ctx, d_boxes_3d, d_scores, d_sel, d_count, max_det, frame_mark,
-                    d_rec, d_count_out):
+                    d_rec, d_count_out, d_corr_offsets=None):
     _lib.check(ctx.lib.dodt_pack_detections(
-        ctx.handle, _p(d_boxes_3d), _p(d_scores), _p(d_sel), _p(d_count), int(max_det),
+        ctx.handle, _p(d_boxes_3d), _p(d_scores), _p(d_corr_offsets), _p(d_sel), _p(d_count),
+        int(max_det),
         float(frame_mark), _p(d_rec), _p(d_count_out)), 'dodt_pack_detections')
 
 
@@ -148,3 +149,40 @@ def fetch_i32_end(ctx, slot, n):
     _lib.check(ctx.lib.dodt_fetch_i32_end(ctx.handle, int(slot), buf, int(n)),
                'dodt_fetch_i32_end')
     return list(buf)
+
+
+def correlation(ctx, d_a, d_b, hwc, max_displacement, stride_2, pad, d_out):
+    _lib.check(ctx.lib.dodt_correlation(
+        ctx.handle, _p(d_a), _p(d_b), int(hwc[0]), int(hwc[1]), int(hwc[2]),
+        int(max_displacement), int(stride_2), int(pad), _p(d_out)), 'dodt_correlation')
+
+
+class FullyConnected(object):
+    """y = act(x w + b) on the device (dodt_fc_*).  w (K,N) row-major, the layout of the
+    TF variable (conv kernels reshaped (kh*kw*cin, cout))."""
+
+    def __init__(self, ctx, w, b, relu):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        if w.ndim != 2 or b.shape != (w.shape[1],):
+            raise ValueError('weights must be (K,N) and bias (N,)')
+        self.ctx, self.K, self.N = ctx, int(w.shape[0]), int(w.shape[1])
+        h = C.c_void_p()
+        _lib.check(ctx.lib.dodt_fc_create(ctx.handle, self.K, self.N, w.ctypes.data_as(C.c_void_p),
+                                          b.ctypes.data_as(C.c_void_p), int(bool(relu)),
+                                          C.byref(h)), 'dodt_fc_create')
+        self.handle = h
+
+    def forward(self, d_x, M, d_y, ldx=None, ldy=None, d_x2=None, d_m=None, ctx=None):
+        c = ctx or self.ctx
+        _lib.check(c.lib.dodt_fc_forward(
+            self.handle, c.handle, _p(d_x), _p(d_x2), int(self.K if ldx is None else ldx),
+            int(M), _p(d_m), _p(d_y), int(self.N if ldy is None else ldy)), 'dodt_fc_forward')
+
+    def flops(self, M):
+        return 2.0 * M * self.K * self.N
+
+    def close(self):
+        if self.handle is not None:
+            self.ctx.lib.dodt_fc_destroy(self.handle)
+            self.handle = None

@@ -4,8 +4,10 @@ Order of work follows the reference's inference call stack:
 create_feed_dict (points -> BEV maps, anchor grid -> empty filter -> projections;
 avod/core/models/dt_rpn_model.py:732-1042) then the graph
 (dt_rpn_model.py:355-730, dt_avod_model.py:128-711).  The dense heads between
-crop and NMS (anchor predictor, stage-2 FC) are "next" rows of SURVEY 8(f): their
-outputs are inputs of this pipeline (`heads`), resident in HBM.
+crop and NMS (anchor predictor, stage-2 FC, correlation branch: SURVEY 8(f) items 1-2)
+run on the device when the pipeline is built with `head_params`; without them their
+outputs are inputs of the pipeline (`heads`, resident in HBM), which is what the
+index-exact parity tests use.
 
 Frame pairs are independent (batch size 1 in the reference, no cross-pair state),
 so a step may carry several pairs: all their frames go through the conv stacks as
@@ -22,17 +24,22 @@ import numpy as np
 
 from dodt_amd import device, ops, synth
 from dodt_amd.core.anchor_generators import grid_anchor_3d_generator as gen
+from dodt_amd.core.avod_fc_layers.fusion_fc_layers import EarlyFusionFcLayers
 from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr, ImgVggPyr
+from dodt_amd.core.models.anchor_predictor import AnchorPredictor
 
 MAX_DET = 100            # avod_nms_size
 REC_COLS = 17            # dt_evaluator.py:1217-1257
+ROI = 7                  # avod_proposal_roi_crop_size
+CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD = 5, 2, 5     # correlation_config; correlation.py:7
+CORR_CH = (2 * (CORR_MAX_DISP // CORR_STRIDE2) + 1) ** 2
 
 
 class FramePairPipeline(object):
     def __init__(self, ctx, cfg, p2=synth.P2, r0_rect=synth.R0_RECT,
                  tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
                  n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None,
-                 pairs_per_step=1, side_streams=None):
+                 pairs_per_step=1, side_streams=None, head_params=None):
         self.ctx = ctx
         self.cfg = cfg
         self.p2 = np.asarray(p2, dtype=np.float64)
@@ -75,9 +82,20 @@ class FramePairPipeline(object):
         self.d_img_in = [ctx.wrap(p + 4 * s * f, (self.img_h, self.img_w, 4))
                          for f in range(self.nf)]
 
-        # ---- work buffers ----------------------------------------------------------------
+        # ---- dense heads (weights shared, scratch per side stream) ------------------------
         f32, i32 = np.float32, np.int32
         N, P = self.n_all, self.P
+        self.rpn_head = self.avod_head = self.corr_head = None
+        if head_params is not None:
+            self.rpn_head = AnchorPredictor(ctx, head_params['rpn'])
+            self.avod_head = EarlyFusionFcLayers(ctx, head_params['avod'])
+            self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'], outputs=('off_out',))
+            self.head_scratch = [dict(rpn=self.rpn_head.make_scratch(N),
+                                      fc=self.avod_head.make_scratch(P),
+                                      corr_map=ctx.empty((self.bev_h, self.bev_w, CORR_CH), f32))
+                                 for _ in self.sides]
+
+        # ---- work buffers ----------------------------------------------------------------
         self.feat = [dict(
             bev_feat=ctx.empty((self.nf, self.bev_h, self.bev_w, 32), f32),
             bev_bneck=ctx.empty((self.nf, self.bev_h, self.bev_w, 1), f32),
@@ -99,7 +117,14 @@ class FramePairPipeline(object):
                 bev_rois=ctx.empty((P, 7, 7, 32), f32), img_rois=ctx.empty((P, 7, 7, 32), f32),
                 boxes_3d=ctx.empty((P, 7), f32), pred_anchors=ctx.empty((P, 6), f32),
                 nms2_boxes=ctx.empty((P, 4), f32), nms2_scores=ctx.empty((P,), f32),
-                det_idx=ctx.empty((MAX_DET,), i32), det_count=ctx.zeros((1,), i32))
+                det_idx=ctx.empty((MAX_DET,), i32), det_count=ctx.zeros((1,), i32),
+                det_scores=ctx.empty((P,), f32))
+            if head_params is not None:
+                b.update(rpn_logits=ctx.empty((N, 2), f32), rpn_offsets=ctx.empty((N, 6), f32),
+                         cls_logits=ctx.empty((P, 2), f32), offsets_4c=ctx.empty((P, 10), f32))
+                if f % 2 == 0:
+                    b.update(corr_rois=ctx.empty((P, ROI, ROI, CORR_CH), f32),
+                             corr_offsets=ctx.empty((P, 3), f32))
             self.fr2[f // self.nf].append(b)
         self.fr = self.fr2[0]          # buffers of the most recently finished step
         self.step_idx = 0
@@ -117,15 +142,18 @@ class FramePairPipeline(object):
         self.d_rec_counts = self.ctx.wrap(cnt_ptr, (self.pairs, 2), np.int32)
 
     # ------------------------------------------------------------------------------------
-    def run(self, d_points, n_points, d_images, heads):
+    def run(self, d_points, n_points, d_images, heads=None):
         """Enqueue one step.  Lists of length 2 * pairs_per_step, frame order
         [pair0 f0, pair0 f1, pair1 f0, ...]: d_points[f] (n,4) float32 velodyne xyzi;
         d_images[f] (H,W,3) uint8; heads[f] dict of device arrays rpn_logits (N,2),
-        rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10).
+        rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10) [, corr_offsets (P,3) on
+        frame 0 of a pair]; None when the pipeline computes the heads itself (head_params).
         Returns the kept-anchor counts of this step.  The detections of the PREVIOUS
         step are complete on the main stream when this returns; call finish() after the
         last step (run(); finish() is the unpipelined form)."""
         main, nf = self.ctx, self.nf
+        if (heads is None) != (self.rpn_head is not None):
+            raise ValueError('pass `heads` exactly when the pipeline has no head_params')
         mean = (ImgVggPyr._R_MEAN, ImgVggPyr._G_MEAN, ImgVggPyr._B_MEAN)
         ns = len(self.sides)
         cur = self.step_idx & 1
@@ -184,7 +212,10 @@ class FramePairPipeline(object):
         img_px = self.img_h * self.img_w
         plane = cfg['ground_plane']
         for f in range(nf):
-            c, b, h, A = self.sides[f % ns], fr[f], heads[f], counts[f]
+            c, b, A = self.sides[f % ns], fr[f], counts[f]
+            computed = heads is None
+            h = b if computed else heads[f]
+            scratch = self.head_scratch[f % ns] if computed else None
             bneck_b = feat['bev_bneck'].offset(4 * bev_px * f, (self.bev_h, self.bev_w, 1))
             bneck_i = feat['img_bneck'].offset(4 * img_px * f, (self.img_h, self.img_w, 1))
             feat_b = feat['bev_feat'].offset(4 * bev_px * 32 * f, (self.bev_h, self.bev_w, 32))
@@ -194,6 +225,9 @@ class FramePairPipeline(object):
                                 (3, 3), b['rpn_bev_roi'])
             ops.crop_and_resize(c, bneck_i, (self.img_h, self.img_w, 1), b['img_norm'], A, None,
                                 (3, 3), b['rpn_img_roi'])
+            if computed:
+                self.rpn_head.forward(c, b['rpn_bev_roi'], b['rpn_img_roi'], A, b['rpn_logits'],
+                                      b['rpn_offsets'], scratch['rpn'])
             # -- a12, a5, a13: decode, project, NMS #1 --------------------------------------
             ops.offset_to_anchor(c, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
             ops.project_anchors_f32(c, b['regressed'], A, None, self.bev_extents_flat, self.p2,
@@ -211,6 +245,22 @@ class FramePairPipeline(object):
                                 b['top_count'], (7, 7), b['bev_rois'])
             ops.crop_and_resize(c, feat_i, (self.img_h, self.img_w, 32), b['top_img'], self.P,
                                 b['top_count'], (7, 7), b['img_rois'])
+            corr_offsets = h.get('corr_offsets') if f % 2 == 0 else None
+            if computed:
+                self.avod_head.forward(c, b['bev_rois'], b['img_rois'], self.P, b['top_count'],
+                                       [b['cls_logits'], b['offsets_4c']], scratch['fc'])
+                if f % 2 == 0:
+                    # T branch: correlate the pair's BEV features, crop with frame 0's
+                    # proposals (dt_rpn_model.py:324-331, dt_avod_model.py:267-273,300-304)
+                    feat_b1 = feat['bev_feat'].offset(4 * bev_px * 32 * (f + 1),
+                                                      (self.bev_h, self.bev_w, 32))
+                    ops.correlation(c, feat_b, feat_b1, (self.bev_h, self.bev_w, 32),
+                                    CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD, scratch['corr_map'])
+                    ops.crop_and_resize(c, scratch['corr_map'], (self.bev_h, self.bev_w, CORR_CH),
+                                        b['top_bev'], self.P, b['top_count'], (ROI, ROI),
+                                        b['corr_rois'])
+                    self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
+                                           [b['corr_offsets']], scratch['fc'])
             # -- a14, a13: box_4c decode, NMS #2 ---------------------------------------------
             ops.box_4c_decode(c, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
                               plane, self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'],
@@ -218,16 +268,26 @@ class FramePairPipeline(object):
             ops.max_fg_logit(c, h['cls_logits'], 2, self.P, b['top_count'], b['nms2_scores'])
             ops.nms(c, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
                     cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
+            # record score = softmax over [background, class] (dt_evaluator.py:1226-1248)
+            ops.softmax_fg(c, h['cls_logits'], self.P, b['top_count'], b['det_scores'])
             ops.pack_detections(
-                c, b['boxes_3d'], b['nms2_scores'], b['det_idx'], b['det_count'], MAX_DET,
+                c, b['boxes_3d'], b['det_scores'], b['det_idx'], b['det_count'], MAX_DET,
                 float(f % 2), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
-                self.d_rec_counts.offset(4 * f, (1,), np.int32))
+                self.d_rec_counts.offset(4 * f, (1,), np.int32), d_corr_offsets=corr_offsets)
 
     def sync(self):
         self.ctx.sync()
 
     def flops_per_step(self):
+        """Conv stacks only (the roofline kernel); see head_flops_per_step."""
         return self.bev_net.flops() + self.img_net.flops()
+
+    def head_flops_per_step(self, anchor_counts=None):
+        if self.rpn_head is None:
+            return 0.0
+        counts = anchor_counts or self.last_anchor_counts
+        return (sum(self.rpn_head.flops(a) for a in counts)
+                + self.nf * self.avod_head.flops(self.P) + self.pairs * self.corr_head.flops(self.P))
 
     def flops_per_pair(self):
         return self.flops_per_step() / self.pairs
@@ -235,3 +295,6 @@ class FramePairPipeline(object):
     def close(self):
         self.bev_net.close()
         self.img_net.close()
+        for hd in (self.rpn_head, self.avod_head, self.corr_head):
+            if hd is not None:
+                hd.close()

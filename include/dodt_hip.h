@@ -199,6 +199,32 @@ int dodt_crop_and_resize(dodt_ctx* ctx, const float* d_image, int H, int W, int 
                          const float* d_boxes, int n, const int32_t* d_n, int crop_h,
                          int crop_w, float* d_out);
 
+/* ---- T branch: correlation of the two frames' BEV feature maps ------------------------
+ * Stands behind avod/core/corr_layers/correlation.py:7-27 -> the Correlation custom op
+ * (avod/core/ops/correlation/correlation_op.cc:53-62, kernel correlation_kernel.cu.cc:
+ * 21-119, padding pad.cu.cc:14-73) with kernel_size 1 and stride_1 1.
+ * d_a, d_b: (H,W,C) float32, C = 32; d_out: (H+2*pad-2*max_displacement,
+ * W+2*pad-2*max_displacement, (2*(max_displacement/stride_2)+1)^2). */
+int dodt_correlation(dodt_ctx* ctx, const float* d_a, const float* d_b, int H, int W, int C,
+                     int max_displacement, int stride_2, int pad, float* d_out);
+
+/* ---- dense heads: fully connected layers (fp32 MFMA) ------------------------------------
+ * y[M][N] = act(x[M][K] . w[K][N] + bias[N]); stands behind slim.fully_connected / the 1x1
+ * and VALID 3x3 slim.conv2d of the heads: avod/core/models/dt_rpn_model.py:445-537 (anchor
+ * predictor), avod/core/avod_fc_layers/fusion_fc_layers.py:136-180 (early fusion heads),
+ * avod/builders/avod_corr_layers_builder.py (correlation offsets head).
+ * w: host, row-major (K,N) = the TF variable's layout (conv kernels reshaped to (kh*kw*cin,
+ * cout)); relu != 0 applies ReLU.  d_x2 (may be NULL): x = (x + x2) / 2, the "mean" fusion
+ * of BEV and image crops.  ldx, ldy: row strides in floats; *d_m (may be NULL) overrides M
+ * on the device.  ctx == NULL in forward uses the creating context's stream. */
+typedef struct dodt_fc dodt_fc;
+int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int relu,
+                   dodt_fc** out);
+int dodt_fc_destroy(dodt_fc* fc);
+int dodt_fc_forward(dodt_fc* fc, dodt_ctx* ctx, const float* d_x, const float* d_x2, int ldx,
+                    int M, const int32_t* d_m, float* d_y, int ldy);
+double dodt_fc_flops(const dodt_fc* fc, int M);
+
 /* ---- a13: NMS -------------------------------------------------------------------------
  * tf.image.non_max_suppression(boxes, scores, max_output_size, iou_threshold),
  * call sites models/dt_rpn_model.py:587-591 and models/dt_avod_model.py:606-613.
@@ -225,13 +251,15 @@ int dodt_gather_rows(dodt_ctx* ctx, const float* d_src, int width, const int32_t
 int dodt_max_fg_logit(dodt_ctx* ctx, const float* d_logits, int n_cls, int n,
                       const int32_t* d_n, float* d_scores_out);
 /* Detection record of one frame, the 17 columns the evaluator writes per box
- * (avod/core/dt_evaluator.py:1217-1257): box_3d(7), score, class index,
- * 7 zeros (the corr-shifted box: T branch, not on this path), frame mark.
+ * (avod/core/dt_evaluator.py:1217-1257): box_3d(7), score, class index, the box shifted by
+ * the correlation head's offsets (x += dx, z += dz, ry += dry; d_corr_offsets (n,3), frame 0
+ * of a pair) or 7 zeros (d_corr_offsets NULL: frame 1), frame mark.
  * Rows d_sel[0..*d_count) of boxes_3d / scores; remaining rows of the
  * (max_det,17) output are zeroed; d_count_out[0] = *d_count. */
 int dodt_pack_detections(dodt_ctx* ctx, const float* d_boxes_3d, const float* d_scores,
-                         const int32_t* d_sel, const int32_t* d_count, int max_det,
-                         float frame_mark, float* d_rec_out, int32_t* d_count_out);
+                         const float* d_corr_offsets, const int32_t* d_sel,
+                         const int32_t* d_count, int max_det, float frame_mark,
+                         float* d_rec_out, int32_t* d_count_out);
 /* Stage-2 decode (models/dt_avod_model.py:464-469,575-603):
  *   anchors_to_box_3d(fix_lw) -> tf_box_3d_to_box_4c -> + offsets ->
  *   tf_box_4c_to_box_3d -> tf_box_3d_to_anchor -> project_to_bev (metres) ->

@@ -33,8 +33,9 @@ def frame_inputs(xyzi, cfg, r0, tr, p2, image_wh):
 
 
 def frame_detections(inp, heads, cfg, p2, image_wh, rpn_nms_size, bev_feat=None,
-                     img_feat=None, bev_bneck=None, img_bneck=None):
-    """The graph half after the extractors, with the dense-head outputs given."""
+                     img_feat=None, bev_bneck=None, img_bneck=None, frame_mark=0):
+    """The graph half after the extractors, with the dense-head outputs given
+    (heads: rpn_logits, rpn_offsets, cls_logits, offsets_4c [, corr_offsets])."""
     A = len(inp['keep'])
     out = {}
     if bev_bneck is not None:
@@ -64,7 +65,17 @@ def frame_detections(inp, heads, cfg, p2, image_wh, rpn_nms_size, bev_feat=None,
                                          cfg['avod_nms_iou_thresh'])
     rec = np.zeros((cfg['avod_nms_size'], 17), np.float32)
     rec[:len(det), :7] = pred[det]
-    rec[:len(det), 7] = s2[det]
+    # dt_evaluator.py:1217-1257: score = max non-background softmax, class index (0: one
+    # class), the corr-shifted box (frame 0 of the pair; zeros on frame 1), frame mark
+    rec[:len(det), 7] = tfops.softmax2(heads['cls_logits'][:n])[det, 1]
+    if heads.get('corr_offsets') is not None and frame_mark == 0:
+        off = heads['corr_offsets'][:n][det].astype(np.float32)
+        shifted = pred[det].astype(np.float32).copy()
+        shifted[:, 0] += off[:, 0]
+        shifted[:, 2] += off[:, 1]
+        shifted[:, 6] += off[:, 2]
+        rec[:len(det), 9:16] = shifted
+    rec[:len(det), 16] = frame_mark
     out.update(regressed=regressed, scores=scores, top_idx=top, top_anchors=top_anchors,
                boxes_3d=pred, pred_anchors=pred_anchors, nms2_boxes=bev_m[:, [1, 0, 3, 2]],
                det_idx=det, records=rec)

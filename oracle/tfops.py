@@ -249,3 +249,33 @@ def non_max_suppression_fast(boxes, scores, max_output_size, iou_threshold):
         sup = (iou > thr) & (area[rest] > 0)
         alive[rest[sup]] = False
     return np.asarray(keep, dtype=np.int32)
+
+
+def correlation(a, b, max_displacement=5, stride_2=2, pad=5):
+    """The reference's Correlation op with kernel_size 1, stride_1 1
+    (avod/core/ops/correlation/correlation_kernel.cu.cc:21-119, pad.cu.cc:14-73):
+    out[y,x,k] = 1/C sum_c Apad[y+d, x+d, c] * Bpad[y+d+s2p, x+d+s2o, c], k over a
+    (2r+1)^2 grid with r = d // stride_2, channel sum sequential in float32 (the CUDA
+    kernel's lane-0 loop over 32 per-lane products).  PARITY UNPINNED: the op is
+    GPU-only and its tests assert nothing."""
+    a = np.asarray(a, dtype=F32)
+    b = np.asarray(b, dtype=F32)
+    h, w, c = a.shape
+    d = max_displacement
+    r = d // stride_2
+    gw = 2 * r + 1
+    oh, ow = h + 2 * pad - 2 * d, w + 2 * pad - 2 * d
+    ap = np.zeros((h + 2 * pad, w + 2 * pad, c), dtype=F32)
+    bp = np.zeros_like(ap)
+    ap[pad:pad + h, pad:pad + w] = a
+    bp[pad:pad + h, pad:pad + w] = b
+    out = np.zeros((oh, ow, gw * gw), dtype=F32)
+    ac = ap[d:d + oh, d:d + ow]
+    for k in range(gw * gw):
+        s2p, s2o = (k // gw - r) * stride_2, (k % gw - r) * stride_2
+        bc = bp[d + s2p:d + s2p + oh, d + s2o:d + s2o + ow]
+        acc = np.zeros((oh, ow), dtype=F32)
+        for ch in range(c):
+            acc = (acc + (ac[:, :, ch] * bc[:, :, ch]).astype(F32)).astype(F32)
+        out[:, :, k] = acc / F32(c)
+    return out

@@ -1,0 +1,159 @@
+"""Correlation op and the dense heads on the GPU against the
+oracle.  Needs an MI355X.
+
+The heads' oracle is pinned by the layer definitions only (TensorFlow is not importable and
+the reference holds no vectors for them: "parity unpinned", see oracle/heads.py); the
+correlation oracle restates the reference's CUDA kernel.  Float tolerance: 1e-4 of the
+output scale (north_star), indices downstream of the heads exact given the same logits."""
+import numpy as np
+import pytest
+
+from dodt_amd import config, device, ops, synth
+from dodt_amd.core.corr_layers.correlation import correlation
+from dodt_amd.pipeline import CORR_CH, MAX_DET, FramePairPipeline
+from oracle import heads as oheads
+from oracle import pipeline as opipe
+from oracle import tfops
+
+pytestmark = pytest.mark.gpu
+C = config.PYRAMID_DODT
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    return device.default_context()
+
+
+def _close(got, want, tol=1e-4):
+    scale = np.abs(want).max() + 1e-12
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= tol * scale, (np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize('hw,md,s2,pad', [((20, 24), 5, 2, 5), ((37, 19), 2, 1, 3),
+                                          ((16, 16), 2, 2, 2), ((33, 70), 5, 2, 5)])
+def test_correlation_matches_oracle(ctx, hw, md, s2, pad):
+    rng = np.random.default_rng(hw[0] * 100 + md)
+    a = rng.normal(size=(1,) + hw + (32,)).astype(np.float32)
+    b = rng.normal(size=(1,) + hw + (32,)).astype(np.float32)
+    got = correlation(a, b, max_displacement=md, stride_2=s2, padding=pad, ctx=ctx)
+    want = tfops.correlation(a[0], b[0], md, s2, pad)
+    assert got.shape[1:] == want.shape
+    _close(got[0], want, 1e-5)
+
+
+def test_correlation_full_size_properties(ctx):
+    """(700,800,32) maps: the zero-displacement channel is mean_c a*b; a == b makes the
+    map symmetric under (dy,dx) -> (-dy,-dx) with the matching pixel shift."""
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(1, 700, 800, 32)).astype(np.float32)
+    out = correlation(a, a, max_displacement=5, stride_2=2, padding=5, ctx=ctx)[0]
+    assert out.shape == (700, 800, CORR_CH)
+    centre = CORR_CH // 2
+    _close(out[:, :, centre], (a[0].astype(np.float64) ** 2).mean(-1).astype(np.float32), 1e-5)
+    # channel (dy,dx)=(+2,+4) at (y,x) equals channel (-2,-4) at (y+2,x+4)
+    ch_p = (1 + 2) * 5 + (2 + 2)
+    ch_m = (-1 + 2) * 5 + (-2 + 2)
+    assert np.array_equal(out[:-2, :-4, ch_p], out[2:, 4:, ch_m])
+    with pytest.raises(NotImplementedError):
+        correlation(a[:, :8, :8], a[:, :8, :8], kernel_size=3)
+
+
+@pytest.mark.parametrize('M,K,N,relu,fuse', [
+    (300, 9, 512, True, True),         # RPN fc6: scalar loads, K padded to 32
+    (5500, 256, 256, True, False),     # RPN fc7
+    (777, 256, 6, False, False),       # RPN reg_fc8
+    (1024, 1568, 2048, True, True),    # stage-2 fc6 with mean fusion
+    (1000, 2048, 10, False, False),    # off_out
+    (513, 1225, 2048, True, False),    # corr fc6: K not a multiple of 4
+    (1, 40, 3, False, False), (64, 32, 128, True, False)])
+def test_fully_connected_matches_oracle(ctx, M, K, N, relu, fuse):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    x2 = rng.normal(size=(M, K)).astype(np.float32) if fuse else None
+    w = rng.normal(0, np.sqrt(2.0 / K), size=(K, N)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=N).astype(np.float32)
+    fc = ops.FullyConnected(ctx, w, b, relu)
+    d_y = ctx.array(np.full((M, N), np.nan, np.float32))
+    fc.forward(ctx.array(x), M, d_y, d_x2=None if x2 is None else ctx.array(x2))
+    want = oheads.fc(oheads.mean_fusion(x, x2) if fuse else x, w, b, relu)
+    _close(d_y.download(), want)
+    fc.close()
+
+
+def test_fully_connected_strides_and_device_row_count(ctx):
+    rng = np.random.default_rng(8)
+    M, K, N, ldx, ldy = 200, 256, 256, 512, 300
+    xs = rng.normal(size=(M, ldx)).astype(np.float32)
+    w = rng.normal(0, 0.1, size=(K, N)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    fc = ops.FullyConnected(ctx, w, b, False)
+    d_y = ctx.array(np.full((M, ldy), 7.0, np.float32))
+    d_m = ctx.array(np.array([150], np.int32))
+    fc.forward(ctx.array(xs).offset(4 * 256, (1,)), M, d_y, ldx=ldx, ldy=ldy, d_m=d_m)
+    got = d_y.download()
+    want = oheads.fc(xs[:, 256:], w, b, False)
+    _close(got[:150, :N], want[:150])
+    assert np.all(got[150:] == 7.0) and np.all(got[:, N:] == 7.0)   # nothing else written
+    with pytest.raises(ValueError):
+        fc.forward(ctx.array(xs), M, d_y, ldx=100, ldy=ldy)
+    fc.close()
+
+
+def test_pair_with_computed_heads_matches_oracle_stagewise(ctx):
+    """Heads computed on the device.  Every dense stage is checked against the oracle on the
+    inputs the device produced for it; the index stages downstream are then checked exactly,
+    the oracle consuming the device's own logits (a logit differing in the last bits may
+    legitimately reorder near-tied NMS candidates, so a free-running comparison would not
+    be a parity statement)."""
+    hp = synth.head_params()
+    pipe = FramePairPipeline(ctx, C, rpn_nms_size=1024, head_params=hp)
+    frames = (0, 2)
+    pts = [synth.lidar_frame(4, f) for f in frames]
+    imgs = [synth.image_frame(4, f) for f in frames]
+    counts = pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts],
+                      [ctx.array(i) for i in imgs])
+    pipe.finish()
+    ctx.sync()
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    bev_feat = pipe.feat[0]['bev_feat'].download()
+    corr_map = tfops.correlation(bev_feat[0], bev_feat[1], 5, 2, 5)
+    for f in range(2):
+        b, A = pipe.fr[f], counts[f]
+        inp = opipe.frame_inputs(pts[f], C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                 synth.IMAGE_WH)
+        assert A == len(inp['keep'])
+        # RPN head on the device's crops
+        obj, off = oheads.rpn_anchor_predictor(b['rpn_bev_roi'].download()[:A],
+                                               b['rpn_img_roi'].download()[:A], hp['rpn'])
+        heads = dict(rpn_logits=b['rpn_logits'].download()[:A],
+                     rpn_offsets=b['rpn_offsets'].download()[:A])
+        _close(heads['rpn_logits'], obj)
+        _close(heads['rpn_offsets'], off)
+        n_top = int(b['top_count'].download()[0])
+        assert n_top > 100
+        # stage-2 heads on the device's crops
+        cls, o4c = oheads.fusion_fc_early(b['bev_rois'].download()[:n_top],
+                                          b['img_rois'].download()[:n_top], hp['avod'])
+        heads.update(cls_logits=b['cls_logits'].download()[:n_top],
+                     offsets_4c=b['offsets_4c'].download()[:n_top])
+        _close(heads['cls_logits'], cls)
+        _close(heads['offsets_4c'], o4c)
+        if f == 0:
+            want_rois = tfops.crop_and_resize(corr_map, b['top_bev'].download()[:n_top], 7, 7)
+            got_rois = b['corr_rois'].download()[:n_top]
+            _close(got_rois, want_rois, 5e-4)
+            heads['corr_offsets'] = b['corr_offsets'].download()[:n_top]
+            _close(heads['corr_offsets'], oheads.corr_fc_early(got_rois, hp['corr']))
+        # everything downstream of the heads, exact on indices
+        want = opipe.frame_detections(inp, heads, C, synth.P2, synth.IMAGE_WH, pipe.P,
+                                      frame_mark=f)
+        assert n_top == len(want['top_idx'])
+        assert np.array_equal(b['top_idx'].download()[:n_top], want['top_idx'])
+        n_det = int(b['det_count'].download()[0])
+        assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
+        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-5, atol=1e-4)
+    assert pipe.head_flops_per_step() > 5e10
+    with pytest.raises(ValueError):
+        pipe.run([], [], [], heads=[{}])
+    pipe.close()

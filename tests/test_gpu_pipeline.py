@@ -52,7 +52,8 @@ def test_frame_pair_matches_oracle(setup):
         assert np.array_equal(bev_in, inp['bev'])
         feats = opipe.extract(inp['bev'], imgs[f], bev_params, img_params, C['img_dims']) \
             if f == 0 else (None, None, None, None)
-        want = opipe.frame_detections(inp, heads[f], C, synth.P2, synth.IMAGE_WH, pipe.P, *feats)
+        want = opipe.frame_detections(inp, heads[f], C, synth.P2, synth.IMAGE_WH, pipe.P, *feats,
+                                      frame_mark=f)
         # --- integer results: exact -------------------------------------------------------
         n_top = int(b['top_count'].download()[0])
         assert n_top == len(want['top_idx'])
@@ -64,9 +65,8 @@ def test_frame_pair_matches_oracle(setup):
         np.testing.assert_allclose(b['regressed'].download()[:A], want['regressed'],
                                    rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(b['boxes_3d'].download()[:n_top], want['boxes_3d'], atol=1e-4)
-        np.testing.assert_allclose(recs[f], want['records'] +
-                                   np.where(np.arange(MAX_DET)[:, None] < n_det,
-                                            np.eye(17, dtype=np.float32)[16] * f, 0), atol=1e-4)
+        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-5, atol=1e-4)
+        assert (np.abs(recs[f][:n_det, 9:16]).sum() > 0) == (f == 0)    # corr-shifted box
         if f == 0:
             for name in ('rpn_bev_roi', 'rpn_img_roi', 'bev_rois', 'img_rois'):
                 got = b[name].download()[:len(want[name])]
