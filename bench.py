@@ -31,12 +31,15 @@ def parse():
     ap.add_argument('--proposals', type=int, default=1024)
     ap.add_argument('--pairs-per-step', type=int, default=1,
                     help='independent frame pairs carried by one step on each GPU')
+    ap.add_argument('--heads', choices=('computed', 'injected'), default='computed',
+                    help='dense heads + correlation branch on the device (the whole path), '
+                         'or their outputs injected from HBM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, synth, budget_s):
+def cpu_baseline(cfg, synth, budget_s, computed_heads=True):
     """The oracle ('port' of the reference's algorithm) timed on this host: whole
     frame pairs -- numpy point path + numpy conv stacks + crop/NMS -- until about
     budget_s seconds have been spent.  Test infrastructure used as a yardstick,
@@ -48,25 +51,33 @@ def cpu_baseline(cfg, synth, budget_s):
         cores = os.cpu_count()
     bev_params = synth.pyramid_params(6, 42)
     img_params = synth.pyramid_params(3, 142)
+    head_params = synth.head_params() if computed_heads else None
     t0 = time.perf_counter()
     frames = 0
     while True:
-        f = frames
-        xyzi = synth.lidar_frame(9, f)
-        img = synth.image_frame(9, f)
-        heads = synth.head_outputs(9, f, 89600, 1024)
-        inp = opipe.frame_inputs(xyzi, cfg, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
-                                 synth.IMAGE_WH)
-        feats = opipe.extract(inp['bev'], img, bev_params, img_params, cfg['img_dims'])
-        opipe.frame_detections(inp, heads, cfg, synth.P2, synth.IMAGE_WH, 1024, *feats)
-        frames += 1
+        inps, feats = [], []
+        for f in (frames, frames + 2):
+            xyzi = synth.lidar_frame(9, f)
+            img = synth.image_frame(9, f)
+            inp = opipe.frame_inputs(xyzi, cfg, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                     synth.IMAGE_WH)
+            inps.append(inp)
+            feats.append(opipe.extract(inp['bev'], img, bev_params, img_params, cfg['img_dims']))
+        if computed_heads:
+            opipe.pair_detections_computed(inps, feats, head_params, cfg, synth.P2,
+                                           synth.IMAGE_WH, 1024)
+        else:
+            for k, f in enumerate((frames, frames + 2)):
+                opipe.frame_detections(inps[k], synth.head_outputs(9, f, 89600, 1024), cfg,
+                                       synth.P2, synth.IMAGE_WH, 1024, *feats[k], frame_mark=k)
+        frames += 2
         el = time.perf_counter() - t0
-        if frames >= 2 and (el > budget_s or frames >= 8):
+        if el > budget_s or frames >= 8:
             break
     return dict(value=(frames / 2.0) / el, unit='frame-pairs/s', cores=int(cores), kind='port',
-                sample='%d synthetic frames (%.1f pairs) through oracle/pipeline.py: numpy '
-                       'point path + numpy/BLAS fp32 conv stacks + crop + NMS' %
-                       (frames, frames / 2.0))
+                sample='%d synthetic frame pairs through oracle/pipeline.py: numpy point path + '
+                       'numpy/BLAS fp32 conv stacks + crop + NMS%s' %
+                       (frames // 2, ' + correlation + dense heads' if computed_heads else ''))
 
 
 def main():
@@ -89,8 +100,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ctx = device.Context(local_rank, stream=stream)
     pps = args.pairs_per_step
+    computed = args.heads == 'computed'
     pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals,
-                             pairs_per_step=pps)
+                             pairs_per_step=pps,
+                             head_params=synth.head_params() if computed else None)
 
     # detection records live in torch memory so that RCCL can ship them
     rec = torch.zeros((pps, 2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
@@ -111,10 +124,11 @@ def main():
             for f in (2 * i, 2 * i + 2):                             # tau = 2
                 pts.append(synth.lidar_frame(seq, f, args.points))
                 imgs.append(ctx.array(synth.image_frame(seq, f)))
-                heads.append({k: ctx.array(v) for k, v in
-                              synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()})
+                if not computed:
+                    heads.append({k: ctx.array(v) for k, v in
+                                  synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()})
         batches.append(dict(pts=[ctx.array(p) for p in pts], n=[len(p) for p in pts],
-                            imgs=imgs, heads=heads))
+                            imgs=imgs, heads=None if computed else heads))
 
     def step(i):
         p = batches[i % n_batches]
@@ -181,14 +195,16 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
                                    'pyramid_cars_with_aug_dt_5_tracking, %d proposals, '
-                                   'S path (heads injected)' % (args.points // 1000,
-                                                                args.proposals),
+                                   '%s' % (args.points // 1000, args.proposals,
+                                           'S+T path: correlation + dense heads on the device'
+                                           if computed else 'S path (heads injected)'),
+                       'head_gflop_per_step': round(pipe.head_flops_per_step() / 1e9, 2),
                        'pairs_per_step_per_gpu': pps, 'parallelism': 'pair-shard x%d' % world,
                        'anchors_kept': pipe.last_anchor_counts},
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(cfg, synth, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(cfg, synth, args.cpu_seconds, computed)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -82,6 +82,41 @@ def frame_detections(inp, heads, cfg, p2, image_wh, rpn_nms_size, bev_feat=None,
     return out
 
 
+def pair_detections_computed(inps, feats, head_params, cfg, p2, image_wh, rpn_nms_size):
+    """A frame pair with the dense heads computed by the oracle too (free-running: used as
+    the CPU baseline and for smoke checks, not for index-exact parity -- see
+    tests/test_gpu_heads.py).  inps / feats: per frame, from frame_inputs / extract."""
+    from oracle import heads as oheads
+    outs = []
+    corr_map = tfops.correlation(feats[0][0], feats[1][0], 5, 2, 5)
+    for f in range(2):
+        inp = inps[f]
+        bev_feat, img_feat, bev_bneck, img_bneck = feats[f]
+        obj, off = oheads.rpn_anchor_predictor(
+            tfops.crop_and_resize(bev_bneck, inp['bev_norm_tf'], 3, 3),
+            tfops.crop_and_resize(img_bneck, inp['img_norm_tf'], 3, 3), head_params['rpn'])
+        A = len(inp['keep'])
+        regressed = oboxes.offset_to_anchor(inp['anchors'], off, np.float32)
+        _, prop_norm = oboxes.project_to_bev(regressed, cfg['bev_extents'], np.float32)
+        top = tfops.non_max_suppression_fast(prop_norm, tfops.softmax2(obj)[:, 1], rpn_nms_size,
+                                             cfg['rpn_nms_iou_thresh'])
+        top_anchors = regressed[top]
+        _, top_bev = oboxes.project_to_bev(top_anchors, cfg['bev_extents'], np.float32)
+        _, top_img = oboxes.project_to_image_space(top_anchors, p2, [image_wh[1], image_wh[0]],
+                                                   dtype=np.float32)
+        cls, o4c = oheads.fusion_fc_early(
+            tfops.crop_and_resize(bev_feat, top_bev[:, [1, 0, 3, 2]], 7, 7),
+            tfops.crop_and_resize(img_feat, top_img[:, [1, 0, 3, 2]], 7, 7), head_params['avod'])
+        heads = dict(rpn_logits=obj, rpn_offsets=off, cls_logits=cls, offsets_4c=o4c)
+        if f == 0:
+            heads['corr_offsets'] = oheads.corr_fc_early(
+                tfops.crop_and_resize(corr_map, top_bev[:, [1, 0, 3, 2]], 7, 7),
+                head_params['corr'])
+        outs.append(frame_detections(inp, heads, cfg, p2, image_wh, rpn_nms_size, frame_mark=f))
+        assert A == len(obj)
+    return outs
+
+
 def extract(bev, img_u8, bev_params, img_params, img_hw):
     """Both extractors + bottlenecks for one frame."""
     bev_feat = oext.vgg_pyramid(bev, bev_params, pad_top=4)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Time the fully connected kernel at the heads' shapes (HIP events)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dodt_amd import device, ops  # noqa: E402
+
+ctx = device.default_context()
+rng = np.random.default_rng(0)
+for M, K, N in [(1024, 1568, 2048), (1024, 2048, 2048), (1024, 1225, 2048), (1024, 2048, 10),
+                (5500, 9, 512), (5500, 256, 256), (5500, 256, 6), (4096, 2048, 2048)]:
+    x = ctx.array(rng.normal(size=(M, K)).astype(np.float32))
+    fc = ops.FullyConnected(ctx, rng.normal(size=(K, N)).astype(np.float32),
+                            np.zeros(N, np.float32), True)
+    y = ctx.empty((M, N), np.float32)
+    for _ in range(3):
+        fc.forward(x, M, y)
+    ctx.sync()
+    reps = 20
+    ctx.timer_start()
+    for _ in range(reps):
+        fc.forward(x, M, y)
+    ms = ctx.timer_stop() / reps
+    print('M=%5d K=%5d N=%5d  %8.1f us  %7.2f TFLOP/s' % (M, K, N, ms * 1e3,
+                                                          fc.flops(M) / ms / 1e9))
+    fc.close()
