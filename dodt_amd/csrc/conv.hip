@@ -34,7 +34,13 @@ struct KernelVariant {
     int blocks_per_cu;  // resident workgroups per CU (registers and LDS permitting)
     void (*launch)(const ConvArgs&, dim3 grid, hipStream_t s);
     hipError_t (*prepare)();
+    bool tail_only = false;  // quarter-size tiles: never a layer's main variant
 };
+
+KernelVariant tail_only(KernelVariant v) {
+    v.tail_only = true;
+    return v;
+}
 
 template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
 struct Inst {
@@ -91,6 +97,11 @@ const std::vector<KernelVariant>& variants() {
         Inst<8, 4, 4, 1, 64, false>::variant(),
         Inst<4, 4, 2, 2, 128, false>::variant(),
         Inst<4, 4, 4, 1, 64, false>::variant(),
+        // quarter-size tiles for tail launches (and tiny layers)
+        tail_only(Inst<32, 4, 4, 1, 32, false>::variant()),
+        tail_only(Inst<16, 4, 4, 1, 32, false>::variant()),
+        tail_only(Inst<8, 4, 4, 1, 32, false>::variant()),
+        tail_only(Inst<4, 4, 4, 1, 32, false>::variant()),
         Inst<16, 4, 4, 1, 32, true>::variant(),
         Inst<8, 4, 4, 1, 32, true>::variant(),
         Inst<4, 4, 4, 1, 32, true>::variant(),
@@ -106,7 +117,7 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
     double best_cost = 1e300;
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
-        if (v.deconv != deconv || v.small_cin != small || Cout % v.BN != 0) continue;
+        if (v.deconv != deconv || v.small_cin != small || v.tail_only || Cout % v.BN != 0) continue;
         // the chunk pipeline needs >= 4 chunks of 8 channels per work item
         if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0 || Cin < 32)) continue;
         const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;
@@ -187,6 +198,14 @@ struct Buffer {
     size_t frame_floats() const { return (size_t)H * W * C; }
 };
 
+// one kernel launch of a layer: a variant and the work items it walks
+struct Launch {
+    int variant = -1;
+    int n_items = 0;
+    int4* d_items = nullptr;
+    float* d_w = nullptr;   // weights blocked for this variant's BN
+};
+
 struct Layer {
     std::string name;
     bool deconv = false;
@@ -195,7 +214,8 @@ struct Layer {
     int src = -1, src_coff = 0;
     int dst = -1, dst_coff = 0;
     int variant = -1;
-    float *d_w = nullptr, *d_scale = nullptr, *d_shift = nullptr;
+    Launch main, tail;   // tail.n_items == 0: single launch
+    float *d_scale = nullptr, *d_shift = nullptr;
     bool loaded = false;
     int real_cin = 0;  // channels that carry data (conv1_1 of the image net: 3 of 4)
 };
@@ -211,7 +231,7 @@ struct dodt_extractor {
     Buffer buf[NBUF];
     std::vector<Layer> layers;
     float* d_bneck_w = nullptr;
-    int* d_counters = nullptr;  // one work-item counter per layer, zeroed every forward
+    int* d_counters = nullptr;  // two work-item counters per layer, zeroed every forward
     float bneck_scale = 1.0f, bneck_shift = 0.0f;
     bool bneck_loaded = false;
     double flops = 0.0;
@@ -227,14 +247,15 @@ int find_layer(dodt_extractor* ex, const char* name) {
 
 int buffer_for_layer_output(const Layer& l) { return l.dst; }
 
-int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h) {
-    const KernelVariant& v = variants()[l.variant];
+int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
+               float* override_out, int out_y0, int out_h) {
+    const KernelVariant& v = variants()[ln.variant];
     const Buffer& src = ex->buf[l.src];
     const Buffer& dst = ex->buf[l.dst];
     ConvArgs a;
     a.in = src.ptr;
     a.out = override_out ? override_out : dst.ptr;
-    a.w = l.d_w;
+    a.w = ln.d_w ? ln.d_w : l.main.d_w;
     a.scale = l.d_scale;
     a.shift = l.d_shift;
     a.H = l.H;
@@ -256,10 +277,10 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
         static const int dbg = getenv("DODT_CONV_DEBUG") ? atoi(getenv("DODT_CONV_DEBUG")) : 0;
         a.debug = dbg;
     }
-    a.counter = ex->d_counters + (&l - ex->layers.data());
-    a.counter_base = ex->d_counters;
-    a.n_tiles = l.Cout / v.BN;
-    a.n_items = a.tiles_x * a.tiles_y * ex->batch * a.n_tiles;
+    a.counter = ex->d_counters + 2 * (&l - ex->layers.data()) + which;
+    a.counter_base = ex->d_counters + 64;
+    a.items = ln.d_items;
+    a.n_items = ln.n_items;
     // persistent workgroups: as many as stay resident, each walks items with that stride
     int grid_x = a.n_items;
     if (!v.small_cin) {
@@ -274,12 +295,82 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
     if (a.debug & 8) {   // diagnostic: print the in-kernel clock of this launch
         unsigned long long h[2] = {0, 0};
         (void)hipStreamSynchronize(ex->ctx->stream);
-        (void)hipMemcpy(h, ex->d_counters + 32, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, ex->d_counters + 96, sizeof(h), hipMemcpyDeviceToHost);
         if (h[1])
             fprintf(stderr, "[dodt] %-16s wg0: %.1f us, shader clock %.3f GHz\n", l.name.c_str(),
                     h[1] / 100.0, (double)h[0] / h[1] * 0.1);
     }
     return DODT_OK;
+}
+
+int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h) {
+    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h);
+    if (rc == DODT_OK && l.tail.n_items > 0)
+        rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h);
+    return rc;
+}
+
+// Work items of a layer.  The main launch walks big tiles; when their count leaves the
+// last round of the persistent grid mostly idle, the surplus tiles are handed to a tail
+// launch that cuts each of them into smaller tiles (same TW; fewer rows and/or channels),
+// so the tail costs a fraction of a round.  Every output element is still summed by one
+// workgroup in one fixed order: results do not depend on how a layer is cut.
+void plan_layer(Layer& l, int batch, int num_cus, std::vector<int4>& main_items,
+                std::vector<int4>& tail_items) {
+    const auto& vs = variants();
+    const KernelVariant& v = vs[l.variant];
+    const int tx = dodt::ceil_div(l.W, v.TW), ty = dodt::ceil_div(l.H, v.TH), nt = l.Cout / v.BN;
+    main_items.clear();
+    tail_items.clear();
+    for (int f = 0; f < batch; ++f)
+        for (int n = 0; n < nt; ++n)
+            for (int y = 0; y < ty; ++y)
+                for (int x = 0; x < tx; ++x) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
+    l.main.variant = l.variant;
+    l.tail.variant = -1;
+    if (v.small_cin) return;
+    static const bool no_tail = getenv("DODT_CONV_NO_TAIL") != nullptr;
+    const int n = (int)main_items.size();
+    const int G = num_cus * v.blocks_per_cu;
+    const int surplus = n % G;
+    if (no_tail || n < G || surplus == 0) return;
+    // companion: same TW and kind, dividing the big tile, as small as possible
+    int best = -1, best_units = 1 << 30;
+    const int big_units = (v.TW * v.TH / 32) * (v.BN / 32);
+    for (size_t i = 0; i < vs.size(); ++i) {
+        const KernelVariant& c = vs[i];
+        if (c.small_cin || c.deconv != v.deconv || c.TW != v.TW || v.TH % c.TH != 0 ||
+            v.BN % c.BN != 0)
+            continue;
+        const int units = (c.TW * c.TH / 32) * (c.BN / 32);
+        if (units < big_units && units < best_units) { best = (int)i; best_units = units; }
+    }
+    if (best < 0) return;
+    const KernelVariant& c = vs[best];
+    const int ry = v.TH / c.TH, rn = v.BN / c.BN;
+    std::vector<int4> small;
+    for (int k = n - surplus; k < n; ++k) {
+        const int4 b = main_items[k];
+        for (int jn = 0; jn < rn; ++jn)
+            for (int jy = 0; jy < ry; ++jy)
+                if (b.z + jy * c.TH < l.H)
+                    small.push_back(make_int4(b.x, b.y * rn + jn, b.z + jy * c.TH, b.w));
+    }
+    // cost of the tail in rounds of the main launch (one round = blocks_per_cu big tiles per
+    // CU).  Measured: small tiles sharing a CU run at the big tiles' rate, a lone small tile
+    // per CU at ~0.78 of it.
+    const double share = (double)best_units / (v.blocks_per_cu * big_units);
+    double cost_small;
+    if ((int)small.size() <= num_cus)
+        cost_small = share / 0.78;
+    else
+        cost_small = dodt::ceil_div((int)small.size(), num_cus * c.blocks_per_cu) *
+                     c.blocks_per_cu * share;
+    cost_small += 0.04;   // second launch
+    if (cost_small >= 1.0) return;
+    main_items.resize(n - surplus);
+    tail_items = small;
+    l.tail.variant = best;
 }
 
 int run_pool(dodt_extractor* ex, int src, int dst) {
@@ -333,7 +424,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
             return DODT_ERR_HIP;
         }
     }
-    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 64 * sizeof(int)));
+    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 128 * sizeof(int)));
     // the pad rows of X0 stay zero for the life of the extractor
     DODT_HIP_CHECK(hipMemsetAsync(ex->buf[X0].ptr, 0,
                                   ex->buf[X0].frame_floats() * batch * sizeof(float), ctx->stream));
@@ -371,12 +462,30 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
             return DODT_ERR_UNSUPPORTED;
         }
     }
+    for (Layer& l : ex->layers) {
+        std::vector<int4> mi, ti;
+        plan_layer(l, batch, ctx->num_cus, mi, ti);
+        for (auto pr : {std::make_pair(&l.main, &mi), std::make_pair(&l.tail, &ti)}) {
+            pr.first->n_items = (int)pr.second->size();
+            if (pr.second->empty()) continue;
+            DODT_HIP_CHECK(hipMalloc(&pr.first->d_items, pr.second->size() * sizeof(int4)));
+            DODT_HIP_CHECK(hipMemcpyAsync(pr.first->d_items, pr.second->data(),
+                                          pr.second->size() * sizeof(int4), hipMemcpyHostToDevice,
+                                          ctx->stream));
+        }
+        DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
+    }
     if (getenv("DODT_DEBUG_PLAN")) {
         for (const Layer& l : ex->layers) {
             const KernelVariant& v = variants()[l.variant];
-            fprintf(stderr, "[dodt] %-16s %4dx%-4d %3d->%-3d TW%d TH%d BN%d CK%d lds %d grid %dx%d\n",
+            fprintf(stderr, "[dodt] %-16s %4dx%-4d %3d->%-3d TW%d TH%d BN%d CK%d lds %d items %d",
                     l.name.c_str(), l.H, l.W, l.Cin, l.Cout, v.TW, v.TH, v.BN, v.CK, v.lds_bytes,
-                    dodt::ceil_div(l.W, v.TW) * dodt::ceil_div(l.H, v.TH) * batch, l.Cout / v.BN);
+                    l.main.n_items);
+            if (l.tail.n_items) {
+                const KernelVariant& c = variants()[l.tail.variant];
+                fprintf(stderr, " + tail TH%d BN%d items %d", c.TH, c.BN, l.tail.n_items);
+            }
+            fprintf(stderr, "\n");
         }
     }
     *out = ex;
@@ -389,7 +498,10 @@ int dodt_extractor_destroy(dodt_extractor* ex) {
     for (int i = 0; i < NBUF; ++i)
         if (ex->buf[i].ptr) (void)hipFree(ex->buf[i].ptr);
     for (Layer& l : ex->layers) {
-        if (l.d_w) (void)hipFree(l.d_w);
+        for (Launch* ln : {&l.main, &l.tail}) {
+            if (ln->d_w) (void)hipFree(ln->d_w);
+            if (ln->d_items) (void)hipFree(ln->d_items);
+        }
         if (l.d_scale) (void)hipFree(l.d_scale);
         if (l.d_shift) (void)hipFree(l.d_shift);
     }
@@ -424,8 +536,14 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     const int cin = l.deconv ? c_b : c_a, cout = l.deconv ? c_a : c_b;
     DODT_REQUIRE(cout == l.Cout && cin <= l.Cin && (cin == l.Cin || li == 0),
                  "layer %s: expected %d->%d channels, got %d->%d", name, l.Cin, l.Cout, cin, cout);
-    const KernelVariant& v = variants()[l.variant];
-    const int nchunks = l.Cin / v.CK, ntiles = l.Cout / v.BN;
+    for (Launch* ln : {&l.main, &l.tail}) {
+    if (ln->variant < 0) continue;
+    if (ln == &l.tail && variants()[l.tail.variant].BN == variants()[l.main.variant].BN) {
+        ln->d_w = nullptr;   // same blocking: share the main launch's copy (set below)
+        continue;
+    }
+    const KernelVariant& v = variants()[ln->variant];
+    const int nchunks = l.Cin / v.CK;
     std::vector<float> blocked((size_t)9 * l.Cin * l.Cout, 0.0f);
     for (int tap = 0; tap < 9; ++tap)
         for (int ci = 0; ci < cin; ++ci)
@@ -441,18 +559,19 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
                           c % 4;
                 blocked[idx] = val;
             }
-    (void)ntiles;
+    if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, blocked.size() * sizeof(float)));
+    DODT_HIP_CHECK(hipMemcpyAsync(ln->d_w, blocked.data(), blocked.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, s));
+    DODT_HIP_CHECK(hipStreamSynchronize(s));
+    }
     std::vector<float> scale(l.Cout), shift(l.Cout);
     for (int co = 0; co < l.Cout; ++co) {
         const float inv = 1.0f / std::sqrt(var[co] + 0.001f);
         scale[co] = inv;
         shift[co] = beta[co] - mean[co] * inv;
     }
-    if (!l.d_w) DODT_HIP_CHECK(hipMalloc(&l.d_w, blocked.size() * sizeof(float)));
     if (!l.d_scale) DODT_HIP_CHECK(hipMalloc(&l.d_scale, l.Cout * sizeof(float)));
     if (!l.d_shift) DODT_HIP_CHECK(hipMalloc(&l.d_shift, l.Cout * sizeof(float)));
-    DODT_HIP_CHECK(hipMemcpyAsync(l.d_w, blocked.data(), blocked.size() * sizeof(float),
-                                  hipMemcpyHostToDevice, s));
     DODT_HIP_CHECK(hipMemcpyAsync(l.d_scale, scale.data(), l.Cout * sizeof(float),
                                   hipMemcpyHostToDevice, s));
     DODT_HIP_CHECK(hipMemcpyAsync(l.d_shift, shift.data(), l.Cout * sizeof(float),
@@ -491,7 +610,7 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
                            (long long)x0.frame_floats() / 4, ex->batch);
         DODT_LAUNCH_CHECK();
     }
-    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 64 * sizeof(int), s));
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 64 * sizeof(int), s));   // diag words stay
     int rc;
     auto L = [&](const char* n) -> const Layer& { return ex->layers[find_layer(ex, n)]; };
 #define RUN(name)                                           \

@@ -56,9 +56,9 @@ struct ConvArgs {
     int Cin, Cout;
     int in_ld, in_coff, out_ld, out_coff;
     long long in_frame_stride, out_frame_stride;  // floats between frames
-    int tiles_x, tiles_y;  // spatial tiles per frame
-    int n_tiles;           // Cout / BN
-    int n_items;           // frames * n_tiles * tiles_x * tiles_y
+    int tiles_x, tiles_y;  // spatial tiles per frame (first-layer kernel)
+    const int4* items;     // MFMA kernel: work items {frame, n-tile, tile y0, tile x0}
+    int n_items;
     int relu;
     int out_y0;    // conv only: rows < out_y0 are dropped, row y lands at y - out_y0
     int out_nhwc;  // 1: NHWC output (last layer), 0: CB8
@@ -136,7 +136,7 @@ __global__ void
 __launch_bounds__(256, (ConvCfg<TW, MTB, WM, WN, BN, DECONV>::kMinWaves))
 conv3x3_mfma_kernel(const ConvArgs a) {
     using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
-    constexpr int TH = Cfg::TH, PW = Cfg::PW;
+    constexpr int PW = Cfg::PW;
     constexpr int MT = Cfg::MT, NT = Cfg::NT, NP = Cfg::NP, NW = Cfg::NW;
     constexpr int NACC = DECONV ? 4 : MT * NT;
     constexpr int PS = kPixStride;
@@ -154,22 +154,16 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = a.Cin / kCK;
     const int in_plane = a.H * a.W * 8;  // floats per input plane
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int items_per_frame = tiles * a.n_tiles;
 
-    // Persistent workgroup.  Work item = (frame, n-tile, spatial tile); the first item is
-    // blockIdx.x, further ones come from an atomic counter (a workgroup that starts late
-    // because another stream holds its CU simply takes fewer items).
+    // Persistent workgroup.  Work item = (frame, n-tile, spatial tile), listed by the host
+    // (a layer is a main launch of big tiles plus, where that evens out the last round, a
+    // tail launch of smaller ones); the first item is blockIdx.x, further ones come from an
+    // atomic counter (a workgroup that starts late because another stream holds its CU
+    // simply takes fewer items).
     struct Item { int frame, ntile, ty0, tx0; };
     auto decode = [&](int it) {
-        Item r;
-        r.frame = it / items_per_frame;
-        it -= r.frame * items_per_frame;
-        r.ntile = it / tiles;
-        it -= r.ntile * tiles;
-        r.ty0 = (it / a.tiles_x) * TH;
-        r.tx0 = (it % a.tiles_x) * TW;
-        return r;
+        const int4 v = a.items[__builtin_amdgcn_readfirstlane(it)];
+        return Item{v.x, v.y, v.z, v.w};
     };
 
     // Staging slot k < NP: patch float4 (tid + 256 k) -> (pixel p, half g); slot NP + k:

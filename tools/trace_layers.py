@@ -15,15 +15,33 @@ IMG = [(n, g * (0.75 / 1.95 if n == 'conv1_1' else 432000.0 / 563200.0)) for n, 
 names = [r['Kernel_Name'] for r in rows]
 bev_idx = [i for i, n in enumerate(names) if 'small_cin' in n and '6>' in n]
 img_idx = [i for i, n in enumerate(names) if 'small_cin' in n and '4>' in n]
+def dur(r):
+    return (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+
+
+def is_tail(r):          # quarter-size tiles of a tail launch: <TW, 4, 4, 1, 32, false>
+    return re.search(r'mfma_kernel<\d+, 4, 4, 1, 32, false>', r['Kernel_Name']) is not None
+
+
 for label, layers, start in (('BEV', BEV, bev_idx[-1]), ('IMG', IMG, img_idx[-1])):
     tot = 0.0
-    for k, (nm, gf) in enumerate(layers):
-        r = rows[start + k]
-        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    k = start
+    t_first = int(rows[start]['Start_Timestamp'])
+    for nm, gf in layers:
+        r = rows[k]
+        d = dur(r)
+        k += 1
+        tail = ''
+        if k < len(rows) and is_tail(rows[k]):
+            gap = (int(rows[k]['Start_Timestamp']) - int(r['End_Timestamp'])) / 1e3
+            tail = ' + tail %.1f us (gap %.1f, grid %d)' % (dur(rows[k]), gap,
+                                                          int(rows[k]['Grid_Size_X']) // 256)
+            d += dur(rows[k]) + gap
+            k += 1
         tot += d
         m = re.search(r'<(.*)>', r['Kernel_Name'])
-        print('%s %-8s %-26s %8.1f us %6.1f TF  grid %6d x %s  vgpr %s+%s lds %s' % (
+        print('%s %-8s %-26s %8.1f us %6.1f TF  grid %6d  vgpr %s%s' % (
             label, nm, m.group(1) if m else r['Kernel_Name'][23:45], d,
-            2 * gf / d * 1e3 if gf else 0, int(r['Grid_Size_X']) // 256, r['Grid_Size_Y'],
-            r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size']))
-    print('%s total %.1f us' % (label, tot))
+            2 * gf / d * 1e3 if gf else 0, int(r['Grid_Size_X']) // 256, r['VGPR_Count'], tail))
+    wall = (int(rows[k - 1]['End_Timestamp']) - t_first) / 1e3
+    print('%s kernels %.1f us, first start to last end %.1f us' % (label, tot, wall))
