@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdodt_hip.so')
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 PTS_VELO_XYZI, PTS_CAM_3XN = 0, 1
 EXTRACTOR_VGG_PYR = 0
+EXTRACTOR_SHARED_GPU = 0x100
 
 
 class DodtError(RuntimeError):
@@ -51,6 +52,7 @@ SIGNATURES = {
     'dodt_version': (_i, []),
     'dodt_last_error': (C.c_char_p, []),
     'dodt_ctx_create': (_i, [_i, C.POINTER(_vp)]),
+    'dodt_ctx_create_high_priority': (_i, [_i, C.POINTER(_vp)]),
     'dodt_ctx_create_on_stream': (_i, [_i, _vp, C.POINTER(_vp)]),
     'dodt_ctx_destroy': (_i, [_vp]),
     'dodt_ctx_sync': (_i, [_vp]),

@@ -14,9 +14,12 @@ from dodt_amd import _lib, device, synth
 class _VggPyr(object):
     PAD_TOP = 0
 
-    def __init__(self, extractor_config=None, ctx=None):
+    def __init__(self, extractor_config=None, ctx=None, shared_gpu=False):
+        """shared_gpu: other streams keep the GPU busy beside this net (the frame-pair
+        pipeline): layers run as single launches (include/dodt_hip.h)."""
         self.config = extractor_config
         self._ctx = ctx
+        self._shared_gpu = bool(shared_gpu)
         self._handle = None
         self._shape = None
         self._params = None
@@ -30,7 +33,9 @@ class _VggPyr(object):
         self._ctx = self._ctx or device.default_context()
         hnd = C.c_void_p()
         _lib.check(self._ctx.lib.dodt_extractor_create(
-            self._ctx.handle, _lib.EXTRACTOR_VGG_PYR, h, w, c, self.PAD_TOP,
+            self._ctx.handle,
+            _lib.EXTRACTOR_VGG_PYR | (_lib.EXTRACTOR_SHARED_GPU if self._shared_gpu else 0),
+            h, w, c, self.PAD_TOP,
             batch, C.byref(hnd)), 'dodt_extractor_create')
         self._handle = hnd
         self._shape = shape

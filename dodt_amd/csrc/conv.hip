@@ -315,7 +315,7 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
 // launch that cuts each of them into smaller tiles (same TW; fewer rows and/or channels),
 // so the tail costs a fraction of a round.  Every output element is still summed by one
 // workgroup in one fixed order: results do not depend on how a layer is cut.
-void plan_layer(Layer& l, int batch, int num_cus, std::vector<int4>& main_items,
+void plan_layer(Layer& l, int batch, int num_cus, bool allow_tail, std::vector<int4>& main_items,
                 std::vector<int4>& tail_items) {
     const auto& vs = variants();
     const KernelVariant& v = vs[l.variant];
@@ -333,7 +333,7 @@ void plan_layer(Layer& l, int batch, int num_cus, std::vector<int4>& main_items,
     const int n = (int)main_items.size();
     const int G = num_cus * v.blocks_per_cu;
     const int surplus = n % G;
-    if (no_tail || n < G || surplus == 0) return;
+    if (no_tail || !allow_tail || n < G || surplus == 0) return;
     // companion: same TW and kind, dividing the big tile, as small as possible
     int best = -1, best_units = 1 << 30;
     const int big_units = (v.TW * v.TH / 32) * (v.BN / 32);
@@ -392,6 +392,8 @@ extern "C" {
 int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c, int pad_top,
                           int batch, dodt_extractor** out) {
     DODT_REQUIRE(ctx && out, "dodt_extractor_create: NULL argument");
+    const bool shared_gpu = (kind & DODT_EXTRACTOR_SHARED_GPU) != 0;
+    kind &= ~DODT_EXTRACTOR_SHARED_GPU;
     DODT_REQUIRE(kind == DODT_EXTRACTOR_VGG_PYR, "dodt_extractor_create: unknown kind %d", kind);
     DODT_REQUIRE(in_h > 0 && in_w > 0 && in_c >= 2 && in_c % 2 == 0 && pad_top >= 0 && batch >= 1,
                  "dodt_extractor_create: bad sizes (in_c must be even)");
@@ -464,7 +466,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     }
     for (Layer& l : ex->layers) {
         std::vector<int4> mi, ti;
-        plan_layer(l, batch, ctx->num_cus, mi, ti);
+        plan_layer(l, batch, ctx->num_cus, !shared_gpu, mi, ti);
         for (auto pr : {std::make_pair(&l.main, &mi), std::make_pair(&l.tail, &ti)}) {
             pr.first->n_items = (int)pr.second->size();
             if (pr.second->empty()) continue;

@@ -41,7 +41,8 @@ int dodt_version(void) { return 1; }
 
 const char* dodt_last_error(void) { return dodt::g_last_error.c_str(); }
 
-static int ctx_create(int device_id, hipStream_t stream, bool external, dodt_ctx** out) {
+static int ctx_create(int device_id, hipStream_t stream, bool external, bool high_priority,
+                      dodt_ctx** out) {
     DODT_REQUIRE(out != nullptr, "dodt_ctx_create: out is NULL");
     int ndev = 0;
     DODT_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -57,7 +58,14 @@ static int ctx_create(int device_id, hipStream_t stream, bool external, dodt_ctx
         c->stream = stream;
         c->owns_stream = false;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        hipError_t e;
+        if (high_priority) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
+        } else {
+            e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        }
         if (e != hipSuccess) {
             delete c;
             dodt::set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -75,11 +83,15 @@ static int ctx_create(int device_id, hipStream_t stream, bool external, dodt_ctx
 }
 
 int dodt_ctx_create(int device_id, dodt_ctx** out) {
-    return ctx_create(device_id, nullptr, false, out);
+    return ctx_create(device_id, nullptr, false, false, out);
+}
+
+int dodt_ctx_create_high_priority(int device_id, dodt_ctx** out) {
+    return ctx_create(device_id, nullptr, false, true, out);
 }
 
 int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out) {
-    return ctx_create(device_id, (hipStream_t)hip_stream, true, out);
+    return ctx_create(device_id, (hipStream_t)hip_stream, true, false, out);
 }
 
 int dodt_ctx_destroy(dodt_ctx* ctx) {

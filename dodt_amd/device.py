@@ -63,10 +63,12 @@ class DeviceArray(object):
 class Context(object):
     """One per GPU per process (include/dodt_hip.h conventions)."""
 
-    def __init__(self, device_id=0, stream=None):
+    def __init__(self, device_id=0, stream=None, high_priority=False):
         self.lib = _lib.load()
         h = C.c_void_p()
-        if stream is None:
+        if stream is None and high_priority:
+            rc = self.lib.dodt_ctx_create_high_priority(int(device_id), C.byref(h))
+        elif stream is None:
             rc = self.lib.dodt_ctx_create(int(device_id), C.byref(h))
         else:
             rc = self.lib.dodt_ctx_create_on_stream(int(device_id),

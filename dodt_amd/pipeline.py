@@ -11,14 +11,17 @@ index-exact parity tests use.
 
 Frame pairs are independent (batch size 1 in the reference, no cross-pair state),
 so a step may carry several pairs: all their frames go through the conv stacks as
-one batch (more workgroups per launch -> fewer idle CUs in the last wave of each
-layer), and the per-frame work before and after the convs runs on side streams,
-one frame each, so the single-workgroup stages (NMS scan) of different frames
-overlap.  Steps are software-pipelined two deep: while the conv stacks of step k
-run on the main streams, the side streams finish step k-1 (crops, decode, NMS);
-feature maps and per-frame buffers are double-buffered for that, and `finish()`
-drains the last step.  Everything stays on the device; the only host round trip
-per step is the kept-anchor count of each frame, fetched while the convs run.
+one batch.  Streams: the two conv stacks each have their own (they run side by
+side); every frame has a side stream for its "prep" (points -> BEV maps, anchors, image
+preprocessing) and its "tail" (crops, heads, decode, NMS), so the single-workgroup
+stages (NMS scan) of different frames overlap (four streams in all at one pair per
+step: the hardware-queue budget of a process).  Steps are
+software-pipelined: while the conv stacks of step k run, the prep streams already
+build the inputs of step k+1 and the tail streams finish step k-1; inputs,
+feature maps, per-frame buffers and detection records are double-buffered by step
+parity for that, and `finish()` drains the last step.  Everything stays on the
+device; the only host round trip per step is the kept-anchor count of each frame,
+fetched one step after it was produced (the host never waits for the GPU).
 """
 import numpy as np
 
@@ -55,8 +58,23 @@ class FramePairPipeline(object):
                                       self.p2, self.image_wh)
         # streams: conv stacks of the two nets side by side, per-frame work on its own
         self.img_ctx = device.Context(ctx.device_id)
-        n_side = min(self.nf, 8) if side_streams is None else int(side_streams)
-        self.sides = [device.Context(ctx.device_id) for _ in range(max(n_side, 1))]
+        n_side = min(self.nf, 2) if side_streams is None else int(side_streams)
+        import os
+        hp = os.environ.get('DODT_PIPE_PRIO', '0') == '1'
+        self.sides = [device.Context(ctx.device_id, high_priority=hp)
+                      for _ in range(max(n_side, 1))]   # tails
+        # ROCm maps a process's streams onto 4 hardware queues; a fifth stream shares a queue
+        # with another one and runs behind its launches (measured: 6 streams 164, 5 streams
+        # 180, 4 streams 191 pairs/s), so by default a frame's prep and tail share a stream
+        mode = os.environ.get('DODT_PIPE_STREAMS', 'shared')
+        if mode == 'shared':      # frame f's prep and tail on one stream
+            self.preps = self.sides
+        elif mode == 'one':       # all preps on one extra stream
+            one = device.Context(ctx.device_id, high_priority=hp)
+            self.preps = [one for _ in self.sides]
+        else:
+            self.preps = [device.Context(ctx.device_id, high_priority=hp)
+                          for _ in range(max(n_side, 1))]
 
         # ---- constants of the configuration, resident on the device ----------------
         boxes = gen.tile_anchors_3d(cfg['area_extents'], cfg['anchor_sizes'],
@@ -69,18 +87,18 @@ class FramePairPipeline(object):
         self.d_cells = ctx.array(cells)
 
         # ---- extractors: every frame of the step is one batch ------------------------
-        self.bev_net = BevVggPyr(ctx=ctx)
+        self.bev_net = BevVggPyr(ctx=ctx, shared_gpu=True)
         self.bev_net.load_params(bev_params or synth.pyramid_params(cfg['bev_depth'], 42))
         self.bev_net._ensure(self.nf, self.bev_h, self.bev_w, cfg['bev_depth'])
-        self.img_net = ImgVggPyr(ctx=self.img_ctx)
+        self.img_net = ImgVggPyr(ctx=self.img_ctx, shared_gpu=True)
         self.img_net.load_params(img_params or synth.pyramid_params(cfg['img_depth'], 142))
         self.img_net._ensure(self.nf, self.img_h, self.img_w, 4)
-        p, s = self.bev_net.input_view()
-        self.d_bev_in = [ctx.wrap(p + 4 * s * f, (self.bev_h, self.bev_w, cfg['bev_depth']))
-                         for f in range(self.nf)]
-        p, s = self.img_net.input_view()
-        self.d_img_in = [ctx.wrap(p + 4 * s * f, (self.img_h, self.img_w, 4))
-                         for f in range(self.nf)]
+        # conv inputs, double-buffered so that step k+1 is prepared under the convs of step k
+        self.in_bev = [ctx.empty((self.nf, self.bev_h, self.bev_w, cfg['bev_depth']), np.float32)
+                       for _ in range(2)]
+        self.in_img = [ctx.empty((self.nf, self.img_h, self.img_w, 4), np.float32)
+                       for _ in range(2)]
+        self.d_bev_in = self._views(self.in_bev[0], (self.bev_h, self.bev_w, cfg['bev_depth']))
 
         # ---- dense heads (weights shared, scratch per side stream) ------------------------
         f32, i32 = np.float32, np.int32
@@ -129,17 +147,24 @@ class FramePairPipeline(object):
         self.fr = self.fr2[0]          # buffers of the most recently finished step
         self.step_idx = 0
         self.pending = None            # step whose tail has not been enqueued yet
-        # detection records of the step: what the all-gather ships
-        self.d_records = ctx.empty((self.pairs, 2, MAX_DET, REC_COLS), f32)
-        self.d_rec_counts = ctx.zeros((self.pairs, 2), i32)
+        # detection records of a step: what the all-gather ships; by step parity
+        self.rec2 = [ctx.empty((self.pairs, 2, MAX_DET, REC_COLS), f32) for _ in range(2)]
+        self.cnt2 = [ctx.zeros((self.pairs, 2), i32) for _ in range(2)]
+        self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]   # last finished step
         self.last_anchor_counts = [0] * self.nf
         ctx.sync()
 
-    def use_record_buffers(self, rec_ptr, cnt_ptr):
-        """Write detection records into caller-owned device memory (e.g. the
-        torch tensor handed to torch.distributed.all_gather)."""
-        self.d_records = self.ctx.wrap(rec_ptr, (self.pairs, 2, MAX_DET, REC_COLS), np.float32)
-        self.d_rec_counts = self.ctx.wrap(cnt_ptr, (self.pairs, 2), np.int32)
+    def _views(self, arr, shape):
+        n = int(np.prod(shape)) * 4
+        return [arr.offset(n * f, shape) for f in range(self.nf)]
+
+    def use_record_buffers(self, rec_ptrs, cnt_ptrs):
+        """Write detection records into caller-owned device memory (e.g. the torch tensors
+        handed to torch.distributed.all_gather): two of each, used by step parity."""
+        self.rec2 = [self.ctx.wrap(p, (self.pairs, 2, MAX_DET, REC_COLS), np.float32)
+                     for p in rec_ptrs]
+        self.cnt2 = [self.ctx.wrap(p, (self.pairs, 2), np.int32) for p in cnt_ptrs]
+        self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]
 
     # ------------------------------------------------------------------------------------
     def run(self, d_points, n_points, d_images, heads=None):
@@ -148,9 +173,10 @@ class FramePairPipeline(object):
         d_images[f] (H,W,3) uint8; heads[f] dict of device arrays rpn_logits (N,2),
         rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10) [, corr_offsets (P,3) on
         frame 0 of a pair]; None when the pipeline computes the heads itself (head_params).
-        Returns the kept-anchor counts of this step.  The detections of the PREVIOUS
-        step are complete on the main stream when this returns; call finish() after the
-        last step (run(); finish() is the unpipelined form)."""
+        Returns the parity (0/1) of the record buffers this step will fill.  The
+        detections of the PREVIOUS step are complete on the main stream when this returns
+        (self.d_records / self.fr / self.last_anchor_counts then describe that step);
+        call finish() after the last step (run(); finish() is the unpipelined form)."""
         main, nf = self.ctx, self.nf
         if (heads is None) != (self.rpn_head is not None):
             raise ValueError('pass `heads` exactly when the pipeline has no head_params')
@@ -158,40 +184,41 @@ class FramePairPipeline(object):
         ns = len(self.sides)
         cur = self.step_idx & 1
         fr, feat = self.fr2[cur], self.feat[cur]
-        # -- a0-a7: data side of the reference's create_feed_dict, one frame per stream.
-        #    (ordered behind the previous step's convs by the waits enqueued below)
+        bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w, self.cfg['bev_depth']))
+        img_in = self._views(self.in_img[cur], (self.img_h, self.img_w, 4))
+        # -- a0-a7: data side of the reference's create_feed_dict, one frame per prep stream.
+        #    These buffers were last read by the tail of step k-2 (same parity): the prep
+        #    streams were told to wait for it when it was enqueued (below).
         for f in range(nf):
-            c, b = self.sides[f % ns], fr[f]
-            ops.bev_slices(c, d_points[f], n_points[f], self.bp, self.d_bev_in[f], b['occ'])
+            c, b = self.preps[f % ns], fr[f]
+            ops.bev_slices(c, d_points[f], n_points[f], self.bp, bev_in[f], b['occ'])
             ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
                               b['keep'], b['count'])
-            ops.fetch_i32_begin(c, b['count'], 1, f // ns)
+            ops.fetch_i32_begin(c, b['count'], 1, 2 * (f // ns) + cur)
             ops.project_anchors_f64(c, self.d_anchor_table, b['keep'], self.n_all, b['count'],
                                     self.bev_extents_flat, self.p2, self.image_wh,
                                     b['bev_norm'], b['img_norm'], b['anchors'])
             ops.img_preprocess(c, d_images[f], (self.image_wh[1], self.image_wh[0]),
-                               (self.img_h, self.img_w), 4, mean, self.d_img_in[f])
-        for s in self.sides:
-            main.wait_for(s)
-            self.img_ctx.wait_for(s)
+                               (self.img_h, self.img_w), 4, mean, img_in[f])
+        for c in self.preps:
+            main.wait_for(c)
+            self.img_ctx.wait_for(c)
         # -- a8-a10: conv stacks, all frames per launch, the two nets side by side --------
-        self.bev_net.forward_device(None, feat['bev_feat'], feat['bev_bneck'])
-        self.img_net.forward_device(None, feat['img_feat'], feat['img_bneck'])
-        # kept-anchor counts arrive while the convs run
-        counts = [ops.fetch_i32_end(self.sides[f % ns], f // ns, 1)[0] for f in range(nf)]
-        self.last_anchor_counts = counts
+        self.bev_net.forward_device(self.in_bev[cur], feat['bev_feat'], feat['bev_bneck'])
+        self.img_net.forward_device(self.in_img[cur], feat['img_feat'], feat['img_bneck'])
         # -- the previous step's tail runs under this step's convs --------------------------
         if self.pending is not None:
             self._tail(self.pending)
-        # everything enqueued on the side streams from here on comes after these convs
+            for i, s in enumerate(self.sides):
+                main.wait_for(s)       # previous step's records are complete on `main`
+                self.preps[i].wait_for(s)   # the NEXT step's prep reuses that tail's buffers
+        self.pending = dict(cur=cur, heads=heads)
+        # the tail of THIS step (next call) starts when these convs are done
         for s in self.sides:
             s.wait_for(main)
             s.wait_for(self.img_ctx)
-        for s in self.sides:
-            main.wait_for(s)           # previous step's records are complete on `main`
-        self.pending = dict(cur=cur, heads=heads, counts=counts)
         self.step_idx += 1
-        return counts
+        return cur
 
     def finish(self):
         """Enqueue the tail of the last step; afterwards self.fr / d_records hold it."""
@@ -200,14 +227,23 @@ class FramePairPipeline(object):
             self.pending = None
         for s in self.sides:
             self.ctx.wait_for(s)
+        self.ctx.wait_for(self.img_ctx)
 
     def _tail(self, st):
         """Stages after the extractors for every frame of step `st` (a11-a14)."""
         cfg, nf = self.cfg, self.nf
         ns = len(self.sides)
-        fr, feat = self.fr2[st['cur']], self.feat[st['cur']]
-        heads, counts = st['heads'], st['counts']
+        cur = st['cur']
+        fr, feat = self.fr2[cur], self.feat[cur]
+        heads = st['heads']
+        # kept-anchor counts of that step: fetched by its prep streams, long complete
+        counts = [ops.fetch_i32_end(self.preps[f % ns], 2 * (f // ns) + cur, 1)[0]
+                  for f in range(nf)]
+        self.last_anchor_counts = counts
         self.fr = fr
+        self.d_records, self.d_rec_counts = self.rec2[cur], self.cnt2[cur]
+        self.d_bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w,
+                                                       self.cfg['bev_depth']))
         bev_px = self.bev_h * self.bev_w
         img_px = self.img_h * self.img_w
         plane = cfg['ground_plane']

@@ -45,6 +45,9 @@ typedef struct dodt_ctx dodt_ctx;
 int dodt_version(void);
 const char* dodt_last_error(void);            /* thread-local, never NULL */
 int dodt_ctx_create(int device_id, dodt_ctx** out);
+/* Own stream at the device's greatest priority: for short latency-critical chains
+ * (per-frame NMS / heads) that share the GPU with long persistent conv launches. */
+int dodt_ctx_create_high_priority(int device_id, dodt_ctx** out);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
 int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out);
 int dodt_ctx_destroy(dodt_ctx* ctx);
@@ -162,6 +165,11 @@ int dodt_img_preprocess(dodt_ctx* ctx, const uint8_t* d_img_u8, int in_h, int in
  * 30-177) plus the 1x1 bottleneck (models/dt_rpn_model.py:298-322). */
 typedef struct dodt_extractor dodt_extractor;
 #define DODT_EXTRACTOR_VGG_PYR 0
+/* OR into `kind`: the extractor shares the GPU with other streams (the frame-pair pipeline
+ * runs both nets side by side).  Layers are then single launches: the tail launches that
+ * even out a layer's last round when it has the GPU to itself only add work when another
+ * stream fills the idle CUs anyway. */
+#define DODT_EXTRACTOR_SHARED_GPU 0x100
 /* in_c: channels of the input tensor as stored (6 for BEV; 4 for the padded
  * image); pad_top: zero rows added on top (4 for BEV 700->704, 0 for images);
  * batch: frames processed per forward call (2 = both frames of a pair). */

@@ -111,12 +111,13 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx):
     frames = (0, 2)
     pts = [synth.lidar_frame(4, f) for f in frames]
     imgs = [synth.image_frame(4, f) for f in frames]
-    counts = pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts],
-                      [ctx.array(i) for i in imgs])
+    cur = pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts],
+                   [ctx.array(i) for i in imgs])
     pipe.finish()
     ctx.sync()
+    counts = pipe.last_anchor_counts
     recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
-    bev_feat = pipe.feat[0]['bev_feat'].download()
+    bev_feat = pipe.feat[cur]['bev_feat'].download()
     corr_map = tfops.correlation(bev_feat[0], bev_feat[1], 5, 2, 5)
     for f in range(2):
         b, A = pipe.fr[f], counts[f]

@@ -25,10 +25,10 @@ def _run(ctx, pipe, seq, frames, n_points=120000):
     d_pts = [ctx.array(p) for p in pts]
     d_imgs = [ctx.array(i) for i in imgs]
     d_heads = [{k: ctx.array(v) for k, v in h.items()} for h in heads]
-    counts = pipe.run(d_pts, [len(p) for p in pts], d_imgs, d_heads)
+    pipe.run(d_pts, [len(p) for p in pts], d_imgs, d_heads)
     pipe.finish()
     ctx.sync()
-    return pts, imgs, heads, counts
+    return pts, imgs, heads, list(pipe.last_anchor_counts)
 
 
 def test_frame_pair_matches_oracle(setup):
