@@ -57,5 +57,6 @@ struct dodt_ctx {
     int num_cus = 256;
     int32_t* pinned = nullptr;       // 8 slots x 16 int32, hipHostMalloc
     hipEvent_t fetch_ev[8] = {};
+    hipEvent_t mark_ev[16] = {};     // timing marks for tools/ (created on first use)
     hipEvent_t join_ev = nullptr;    // recorded on this stream for dodt_ctx_wait_for
 };

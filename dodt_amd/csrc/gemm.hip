@@ -13,11 +13,16 @@
 //     features of a sample (128 B).
 //   * weights are pre-blocked on the host as [n-tile][K/8][h][BN][4] (the two MFMA k-lanes
 //     take k = s and s + 4): one ds_read_b128 per operand feeds four MFMAs, like the conv.
-//   * a stage = 32 k; x tile [BM][32 + 4 pad] (conflict-free b128 reads), two LDS buffers,
-//     the next stage's global loads are in registers while the current one computes.
+//   * a stage = 32 k; x tile [BM][32 + 4 pad] (conflict-free b128 reads), two LDS buffers;
+//     while stage s computes, stage s+1 moves from registers to the other buffer and the
+//     loads of stage s+2 are issued, both spread over the MFMAs; fragments of the next
+//     k-block are read before the current one's MFMAs (one barrier per stage).
 //   * optional second input: x = (x1 + x2) / 2, the heads' "mean" fusion, folded into the
 //     load of the first layer (tf.reduce_sum over the two crops / 2.0).
 #include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "common.h"
@@ -27,8 +32,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBK = 32;       // k per stage
-constexpr int kXS = kBK + 4;  // LDS floats per x row
+constexpr int kKAlign = 64;   // K is padded to this (the largest stage depth)
 
 struct GemmArgs {
     const float* x;
@@ -40,10 +44,11 @@ struct GemmArgs {
     const int* d_m;    // may be NULL: rows >= *d_m are skipped
 };
 
-template <int BM, int BN, int WM, int WN, bool XVEC>
+template <int BM, int BN, int WM, int WN, bool XVEC, int WBN, int kBK, bool FUSE>
 __global__ void __launch_bounds__(256)
 fc_mfma_kernel(const GemmArgs a) {
     constexpr int MT = BM / 32 / WM, NT = BN / 32 / WN;
+    constexpr int kXS = kBK + 4;             // LDS floats per x row
     constexpr int XITEMS = BM * (kBK / 4);   // float4 per stage
     constexpr int WITEMS = kBK * BN / 4;
     constexpr int NX = (XITEMS + 255) / 256, NW = (WITEMS + 255) / 256;
@@ -57,55 +62,72 @@ fc_mfma_kernel(const GemmArgs a) {
     const int M = a.d_m ? min(*a.d_m, a.M) : a.M;
     if (m0 >= M) return;
     const int nstages = a.Kp / kBK;
-    const f32x4* wblk = reinterpret_cast<const f32x4*>(a.w) + (size_t)nt0 * (a.Kp / 8) * 2 * BN;
+    // weights are blocked WBN columns wide; this kernel's BN columns are a slice of them
+    static_assert(WBN % BN == 0, "tile must divide the blocked width");
+    const f32x4* wblk = reinterpret_cast<const f32x4*>(a.w) +
+                        (size_t)(nt0 * BN / WBN) * (a.Kp / 8) * 2 * WBN + (nt0 * BN) % WBN;
 
-    f32x4 px[NX], pw[NW];
-    auto load_stage = [&](int st) {
+    // staging slot j < NX: x float4 (tid + 256 j); slot NX + j: weight float4 (tid + 256 j).
+    // Loads are unconditional (clamped addresses), zero-fill happens by select.
+    f32x4 pre[NX + NW];
+    constexpr int NSLOT = NX + NW;
+    // per-slot addressing, hoisted out of the k loop (the loop body must leave the issue
+    // slots between MFMAs to the loads and LDS writes, not to integer arithmetic)
+    int g_off[NSLOT];   // x: float offset of (row, k-quad) at stage 0; w: float4 offset
+    int l_off[NSLOT];   // LDS float offset inside a buffer
+    int k_q[NX];        // first k of the slot's quad within a stage
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            const int t = tid + k * 256;
+    for (int j = 0; j < NSLOT; ++j) {
+        if (j < NX) {
+            const int t = tid + j * 256;
             const int row = min(t / (kBK / 4), BM - 1), q = t % (kBK / 4);
             const int m = min(m0 + row, M - 1);          // clamp: surplus rows are never stored
-            const int kk = st * kBK + q * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            g_off[j] = m * a.ldx + q * 4;
+            k_q[j < NX ? j : 0] = q * 4;
+            l_off[j] = row * kXS + q * 4;
+        } else {
+            const int t = min(tid + (j - NX) * 256, WITEMS - 1);
+            g_off[j] = (t / BN) * WBN + t % BN;
+            l_off[j] = BM * kXS + t * 4;
+        }
+    }
+    // loads only ISSUE here; averaging (FUSE) and the zero fill of the K padding happen when
+    // the registers are written to LDS a stage later, so no load is waited for on the spot
+    f32x4 pre2[FUSE ? NX : 1];
+    auto load_slot = [&](int j, int st) {
+        if (j < NX) {
+            const int kk = st * kBK + k_q[j < NX ? j : 0];
             if constexpr (XVEC) {
-                if (kk < a.K) {
-                    v = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + kk);
-                    if (a.x2) {
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(a.x2 + (size_t)m * a.ldx + kk);
-                        v = (v + u) / 2.0f;
-                    }
-                }
+                const int back = max(kk + 4 - a.K, 0);   // > 0 only in the padded last stage
+                pre[j] = *reinterpret_cast<const f32x4*>(a.x + g_off[j] + st * kBK - back);
+                if constexpr (FUSE)
+                    pre2[j < NX ? j : 0] =
+                        *reinterpret_cast<const f32x4*>(a.x2 + g_off[j] + st * kBK - back);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (kk + e < a.K) {
-                        float s = a.x[(size_t)m * a.ldx + kk + e];
-                        if (a.x2) s = (s + a.x2[(size_t)m * a.ldx + kk + e]) / 2.0f;
-                        v[e] = s;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const int back = max(kk + e + 1 - a.K, 0);
+                    pre[j][e] = a.x[g_off[j] + st * kBK + e - back];
+                    if constexpr (FUSE)
+                        pre2[j < NX ? j : 0][e] = a.x2[g_off[j] + st * kBK + e - back];
+                }
             }
-            px[k] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int t = min(tid + k * 256, WITEMS - 1);
-            pw[k] = wblk[(size_t)st * WITEMS + t];
+        } else {
+            pre[j] = wblk[(size_t)st * (kBK / 4 * WBN) + g_off[j]];
         }
     };
-    auto store_stage = [&](int buf) {
-        float* sX = smem + buf * kBuf;
-        float* sW = sX + BM * kXS;
+    auto store_slot = [&](int j, int buf, int st) {   // st: the stage the registers hold
+        if (j < NX) {
+            f32x4 v = pre[j];
+            if constexpr (FUSE) v = (v + pre2[j < NX ? j : 0]) / 2.0f;
+            const int kk = st * kBK + k_q[j < NX ? j : 0];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            const int t = tid + k * 256;
-            if (t < XITEMS)
-                *reinterpret_cast<f32x4*>(sX + (t / (kBK / 4)) * kXS + (t % (kBK / 4)) * 4) = px[k];
-        }
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int t = tid + k * 256;
-            if (t < WITEMS) reinterpret_cast<f32x4*>(sW)[t] = pw[k];
+            for (int e = 0; e < 4; ++e) v[e] = (kk + e < a.K) ? v[e] : 0.0f;
+            if (XITEMS % 256 == 0 || tid + j * 256 < XITEMS)
+                *reinterpret_cast<f32x4*>(smem + buf * kBuf + l_off[j]) = v;
+        } else {
+            if (WITEMS % 256 == 0 || tid + (j - NX) * 256 < WITEMS)
+                *reinterpret_cast<f32x4*>(smem + buf * kBuf + l_off[j]) = pre[j];
         }
     };
 
@@ -115,38 +137,68 @@ fc_mfma_kernel(const GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
 
-    load_stage(0);
-    store_stage(0);
+    // pipeline: stage st computes from LDS buffer st&1; in the shadow of its MFMAs the
+    // registers (stage st+1) are written to the other buffer and refilled with stage st+2
+    const int last = nstages - 1;
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) load_slot(j, 0);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) store_slot(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) load_slot(j, min(1, last));
     __syncthreads();
+    constexpr int NQ = kBK / 8;
+    constexpr int SPQ = (NSLOT + NQ - 1) / NQ;   // staging slots per k-block of 8
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nstages) load_stage(st + 1);   // in flight during the MFMAs
         const float* sX = smem + buf * kBuf;
         const float* sW = sX + BM * kXS;
+        const int st2 = min(st + 2, last);       // surplus loads re-read the last stage
+        f32x4 xf[2][MT], wf[2][NT];
 #pragma unroll
-        for (int q = 0; q < kBK / 8; ++q) {
-            f32x4 xf[MT], wf[NT];
+        for (int mt = 0; mt < MT; ++mt)
+            xf[0][mt] = *reinterpret_cast<const f32x4*>(sX + ((wm * MT + mt) * 32 + li) * kXS + lh * 4);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                xf[mt] = *reinterpret_cast<const f32x4*>(
-                    sX + ((wm * MT + mt) * 32 + li) * kXS + q * 8 + lh * 4);
+        for (int nt = 0; nt < NT; ++nt)
+            wf[0][nt] = *reinterpret_cast<const f32x4*>(sW + (lh * BN + (wn * NT + nt) * 32 + li) * 4);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const f32x4*>(
-                    sW + ((q * 2 + lh) * BN + (wn * NT + nt) * 32 + li) * 4);
+        for (int q = 0; q < NQ; ++q) {
+            const int cb = q & 1, nb = cb ^ 1;
+            if (q + 1 < NQ) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int mt = 0; mt < MT; ++mt)
+                    xf[nb][mt] = *reinterpret_cast<const f32x4*>(
+                        sX + ((wm * MT + mt) * 32 + li) * kXS + (q + 1) * 8 + lh * 4);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wf[nb][nt] = *reinterpret_cast<const f32x4*>(
+                        sW + (((q + 1) * 2 + lh) * BN + (wn * NT + nt) * 32 + li) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next fragments' reads above the MFMAs
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            xf[mt][s], wf[nt][s], acc[mt * NT + nt], 0, 0, 0);
+                            xf[cb][mt][s], wf[cb][nt][s], acc[mt * NT + nt], 0, 0, 0);
+#pragma unroll
+            for (int j = q * SPQ; j < (q + 1) * SPQ && j < NSLOT; ++j) {
+                store_slot(j, buf ^ 1, min(st + 1, last));
+                load_slot(j, st2);
+            }
+#pragma unroll
+            for (int s = 2; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            xf[cb][mt][s], wf[cb][nt][s], acc[mt * NT + nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (st + 1 < nstages) {
-            store_stage(buf ^ 1);   // the other buffer: last read before the previous barrier
-            __syncthreads();
-        }
+        __syncthreads();   // buffer buf^1 complete, buffer buf free
     }
     // epilogue: bias + activation; lane = feature, registers = samples
 #pragma unroll
@@ -167,30 +219,33 @@ fc_mfma_kernel(const GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WBN = BN, int kBK = 32>
 int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
-    constexpr size_t lds = 2 * (size_t)(BM * kXS + kBK * BN) * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(BM * (kBK + 4) + kBK * BN) * sizeof(float);
     const bool vec = (a.ldx % 4 == 0) && (a.K % 4 == 0);
     dim3 grid(dodt::ceil_div(a.M, BM), Npad / BN);
-    if (vec) {
-        static bool p = false;
-        if (!p) {
-            DODT_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&fc_mfma_kernel<BM, BN, WM, WN, true>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            p = true;
+    auto go = [&](auto kernel) -> hipError_t {
+        static std::mutex mu;
+        static std::set<const void*> prepared;   // one attribute call per kernel
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!prepared.count(reinterpret_cast<const void*>(kernel))) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds);
+                if (e != hipSuccess) return e;
+                prepared.insert(reinterpret_cast<const void*>(kernel));
+            }
         }
-        hipLaunchKernelGGL((fc_mfma_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, s, a);
-    } else {
-        static bool p = false;
-        if (!p) {
-            DODT_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&fc_mfma_kernel<BM, BN, WM, WN, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            p = true;
-        }
-        hipLaunchKernelGGL((fc_mfma_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, s, a);
-    }
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (vec && a.x2) e = go(&fc_mfma_kernel<BM, BN, WM, WN, true, WBN, kBK, true>);
+    else if (vec) e = go(&fc_mfma_kernel<BM, BN, WM, WN, true, WBN, kBK, false>);
+    else if (a.x2) e = go(&fc_mfma_kernel<BM, BN, WM, WN, false, WBN, kBK, true>);
+    else e = go(&fc_mfma_kernel<BM, BN, WM, WN, false, WBN, kBK, false>);
+    DODT_HIP_CHECK(e);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
 }
@@ -215,7 +270,7 @@ int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bia
     f->K = K;
     f->N = N;
     f->relu = relu;
-    f->Kp = (int)dodt::align_up((size_t)K, kBK);
+    f->Kp = (int)dodt::align_up((size_t)K, kKAlign);
     f->BN = (N >= 128) ? 128 : 32;
     f->Npad = (int)dodt::align_up((size_t)N, (size_t)f->BN);
     // blocked weights [n-tile][Kp/8][h][BN][4]; k = 8q + 4h + s
@@ -261,7 +316,16 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
     a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = ldy; a.relu = f->relu;
     a.d_m = d_m;
     hipStream_t s = (ctx ? ctx : f->ctx)->stream;
-    if (f->BN == 128) return launch_fc<64, 128, 2, 2>(s, a, f->Npad);
+    if (f->BN == 128) {
+        // tile shapes measured at the heads' sizes (M = 1024, N = K = 2048): 64x128 with a
+        // 64-deep stage 97 TFLOP/s; 64x64 tiles and 32-deep stages within 3 % of it; 128x128
+        // (2x2 MFMA tiles per wave) 106 at M = 4096 but only 128 workgroups at M = 1024
+        static const int tile = getenv("DODT_FC_TILE") ? atoi(getenv("DODT_FC_TILE")) : 0;
+        if (tile == 256) return launch_fc<128, 128, 2, 2, 128, 32>(s, a, f->Npad);
+        if (tile == 64) return launch_fc<64, 64, 2, 2, 128>(s, a, f->Npad);
+        if (tile == 32) return launch_fc<64, 128, 2, 2, 128, 32>(s, a, f->Npad);
+        return launch_fc<64, 128, 2, 2, 128, 64>(s, a, f->Npad);
+    }
     return launch_fc<128, 32, 4, 1>(s, a, f->Npad);
 }
 

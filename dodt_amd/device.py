@@ -98,6 +98,16 @@ class Context(object):
         """Later work on this context waits for what `other` has enqueued so far."""
         _lib.check(self.lib.dodt_ctx_wait_for(self.handle, other.handle), 'dodt_ctx_wait_for')
 
+    def mark(self, slot):
+        _lib.check(self.lib.dodt_mark(self.handle, int(slot)), 'dodt_mark')
+
+    def elapsed_ms(self, slot, to_ctx, to_slot):
+        """GPU time from this context's mark `slot` to `to_ctx`'s mark `to_slot`."""
+        ms = C.c_float()
+        _lib.check(self.lib.dodt_mark_elapsed(self.handle, int(slot), to_ctx.handle, int(to_slot),
+                                              C.byref(ms)), 'dodt_mark_elapsed')
+        return ms.value
+
     def timer_start(self):
         _lib.check(self.lib.dodt_timer_start(self.handle), 'timer_start')
 

@@ -152,7 +152,17 @@ class FramePairPipeline(object):
         self.cnt2 = [ctx.zeros((self.pairs, 2), i32) for _ in range(2)]
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]   # last finished step
         self.last_anchor_counts = [0] * self.nf
+        self.mark_steps = ()           # tools/pipe_marks.py: steps whose stages get timing marks
+        self.marks = {}                # name -> (context, slot)
         ctx.sync()
+
+    def _mark(self, c, step, name):
+        """Timing mark `name` of step `step` on context c (only for steps in mark_steps)."""
+        if step in self.mark_steps:
+            slot = sum(1 for (cc, _) in self.marks.values() if cc is c)
+            if slot < 16:
+                c.mark(slot)
+                self.marks['%d:%s' % (step, name)] = (c, slot)
 
     def _views(self, arr, shape):
         n = int(np.prod(shape)) * 4
@@ -189,8 +199,10 @@ class FramePairPipeline(object):
         # -- a0-a7: data side of the reference's create_feed_dict, one frame per prep stream.
         #    These buffers were last read by the tail of step k-2 (same parity): the prep
         #    streams were told to wait for it when it was enqueued (below).
+        k = self.step_idx
         for f in range(nf):
             c, b = self.preps[f % ns], fr[f]
+            self._mark(c, k, 'prep%d_start' % f)
             ops.bev_slices(c, d_points[f], n_points[f], self.bp, bev_in[f], b['occ'])
             ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
                               b['keep'], b['count'])
@@ -200,19 +212,24 @@ class FramePairPipeline(object):
                                     b['bev_norm'], b['img_norm'], b['anchors'])
             ops.img_preprocess(c, d_images[f], (self.image_wh[1], self.image_wh[0]),
                                (self.img_h, self.img_w), 4, mean, img_in[f])
+            self._mark(c, k, 'prep%d_end' % f)
         for c in self.preps:
             main.wait_for(c)
             self.img_ctx.wait_for(c)
         # -- a8-a10: conv stacks, all frames per launch, the two nets side by side --------
+        self._mark(main, k, 'bev_start')
+        self._mark(self.img_ctx, k, 'img_start')
         self.bev_net.forward_device(self.in_bev[cur], feat['bev_feat'], feat['bev_bneck'])
         self.img_net.forward_device(self.in_img[cur], feat['img_feat'], feat['img_bneck'])
+        self._mark(main, k, 'bev_end')
+        self._mark(self.img_ctx, k, 'img_end')
         # -- the previous step's tail runs under this step's convs --------------------------
         if self.pending is not None:
             self._tail(self.pending)
             for i, s in enumerate(self.sides):
                 main.wait_for(s)       # previous step's records are complete on `main`
                 self.preps[i].wait_for(s)   # the NEXT step's prep reuses that tail's buffers
-        self.pending = dict(cur=cur, heads=heads)
+        self.pending = dict(cur=cur, heads=heads, step=k)
         # the tail of THIS step (next call) starts when these convs are done
         for s in self.sides:
             s.wait_for(main)
@@ -252,6 +269,7 @@ class FramePairPipeline(object):
             computed = heads is None
             h = b if computed else heads[f]
             scratch = self.head_scratch[f % ns] if computed else None
+            self._mark(c, st['step'], 'tail%d_start' % f)
             bneck_b = feat['bev_bneck'].offset(4 * bev_px * f, (self.bev_h, self.bev_w, 1))
             bneck_i = feat['img_bneck'].offset(4 * img_px * f, (self.img_h, self.img_w, 1))
             feat_b = feat['bev_feat'].offset(4 * bev_px * 32 * f, (self.bev_h, self.bev_w, 32))
@@ -273,6 +291,7 @@ class FramePairPipeline(object):
                     cfg['rpn_nms_iou_thresh'], b['top_idx'], b['top_count'])
             ops.gather_rows(c, b['regressed'], 6, b['top_idx'], self.P, b['top_count'],
                             b['top_anchors'])
+            self._mark(c, st['step'], 'tail%d_nms1' % f)
             # -- stage 2: project proposals, 7x7 crops --------------------------------------
             ops.project_anchors_f32(c, b['top_anchors'], self.P, b['top_count'],
                                     self.bev_extents_flat, self.p2, self.image_wh,
@@ -297,6 +316,7 @@ class FramePairPipeline(object):
                                         b['corr_rois'])
                     self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
                                            [b['corr_offsets']], scratch['fc'])
+            self._mark(c, st['step'], 'tail%d_heads' % f)
             # -- a14, a13: box_4c decode, NMS #2 ---------------------------------------------
             ops.box_4c_decode(c, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
                               plane, self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'],
@@ -310,6 +330,7 @@ class FramePairPipeline(object):
                 c, b['boxes_3d'], b['det_scores'], b['det_idx'], b['det_count'], MAX_DET,
                 float(f % 2), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
                 self.d_rec_counts.offset(4 * f, (1,), np.int32), d_corr_offsets=corr_offsets)
+            self._mark(c, st['step'], 'tail%d_end' % f)
 
     def sync(self):
         self.ctx.sync()

@@ -52,6 +52,10 @@ int dodt_ctx_create_high_priority(int device_id, dodt_ctx** out);
 int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out);
 int dodt_ctx_destroy(dodt_ctx* ctx);
 int dodt_ctx_sync(dodt_ctx* ctx);
+/* Timing marks (16 per context) for stream-level timelines: record one on ctx's stream;
+ * elapsed GPU time between two marks, possibly of different contexts (waits for `to`). */
+int dodt_mark(dodt_ctx* ctx, int slot);
+int dodt_mark_elapsed(dodt_ctx* from, int from_slot, dodt_ctx* to, int to_slot, float* ms);
 /* Stream-level join: work enqueued on ctx AFTER this call starts only when
  * everything enqueued on `other` BEFORE this call has finished (hipEventRecord on
  * other's stream + hipStreamWaitEvent on ctx's stream; the host does not block).
