@@ -248,7 +248,7 @@ int find_layer(dodt_extractor* ex, const char* name) {
 int buffer_for_layer_output(const Layer& l) { return l.dst; }
 
 int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
-               float* override_out, int out_y0, int out_h) {
+               float* override_out, int out_y0, int out_h, float* bneck_out) {
     const KernelVariant& v = variants()[ln.variant];
     const Buffer& src = ex->buf[l.src];
     const Buffer& dst = ex->buf[l.dst];
@@ -281,6 +281,11 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.counter_base = ex->d_counters + 64;
     a.items = ln.d_items;
     a.n_items = ln.n_items;
+    a.bneck_w = bneck_out ? ex->d_bneck_w : nullptr;
+    a.bneck_out = bneck_out;
+    a.bneck_scale = ex->bneck_scale;
+    a.bneck_shift = ex->bneck_shift;
+    a.bneck_frame_stride = (long long)out_h * dst.W;
     // persistent workgroups: as many as stay resident, each walks items with that stride
     int grid_x = a.n_items;
     if (!v.small_cin) {
@@ -303,10 +308,11 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     return DODT_OK;
 }
 
-int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h) {
-    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h);
+int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h,
+              float* bneck_out = nullptr) {
+    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h, bneck_out);
     if (rc == DODT_OK && l.tail.n_items > 0)
-        rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h);
+        rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h, bneck_out);
     return rc;
 }
 
@@ -629,8 +635,14 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
     RUN("upconv1");
 #undef RUN
     // last layer writes straight into the caller's buffer, pad rows sliced off
-    if ((rc = run_layer(ex, L("pyramid_fusion1"), d_feat_out, ex->pad_top, ex->in_h))) return rc;
-    if (d_bottleneck_out) {
+    // ... and, fused into its epilogue, the 1x1 bottleneck (dt_rpn_model.py:298-322)
+    const Layer& last = L("pyramid_fusion1");
+    const bool fuse = d_bottleneck_out && variants()[last.main.variant].BN == 32 &&
+                      (last.tail.n_items == 0 || variants()[last.tail.variant].BN == 32);
+    if ((rc = run_layer(ex, last, d_feat_out, ex->pad_top, ex->in_h,
+                        fuse ? d_bottleneck_out : nullptr)))
+        return rc;
+    if (d_bottleneck_out && !fuse) {
         const long long n_pix = (long long)ex->batch * ex->in_h * ex->in_w;
         hipLaunchKernelGGL(bottleneck32_kernel, dim3((unsigned)((n_pix * 8 + 255) / 256)),
                            dim3(256), 0, s, d_feat_out, n_pix, ex->d_bneck_w, ex->bneck_scale,

@@ -64,6 +64,12 @@ struct ConvArgs {
     int out_nhwc;  // 1: NHWC output (last layer), 0: CB8
     int* counter;  // work-item counter of this launch (zeroed by the host beforehand)
     int* counter_base;  // start of the counter block (words 32.. are diagnostics)
+    // 1x1 bottleneck fused into the last layer's epilogue (NHWC output, Cout == BN == 32):
+    // bneck_out[pixel] = relu(bneck_scale * sum_c bneck_w[c] * y[pixel][c] + bneck_shift)
+    const float* bneck_w;          // NULL: no bottleneck
+    float* bneck_out;              // (frames, H - out_y0, W)
+    float bneck_scale, bneck_shift;
+    long long bneck_frame_stride;  // floats between frames of bneck_out
     int debug;     // ablation switches for tools/ (0 in production): 1 = no epilogue
                    // stores, 2 = no global loads in the K loop, 4 = no MFMAs
 };
@@ -107,7 +113,8 @@ __device__ __forceinline__ f32x16 mfma32(float w, float x, f32x16 c) {
 // Lane (li = pixel, lh): register group g = r>>2 holds channels c0 + 8g + 4lh + (r&3).
 __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const f32x16& acc,
                                            int c0, int lh, int y, int x, int out_w,
-                                           long long plane_stride, bool ok) {
+                                           long long plane_stride, bool ok, int frame = 0) {
+    float dot = 0.0f;   // this lane's 16 channels of the fused 1x1 bottleneck
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c = c0 + 8 * g + 4 * lh;
@@ -119,6 +126,13 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const 
             float t = acc[4 * g + k] * sc[k] + sh[k];
             v[k] = a.relu ? fmaxf(t, 0.0f) : t;
         }
+        if (a.bneck_w) {
+            const f32x4 bw = *reinterpret_cast<const f32x4*>(a.bneck_w + c);
+            dot += v[0] * bw[0];
+            dot += v[1] * bw[1];
+            dot += v[2] * bw[2];
+            dot += v[3] * bw[3];
+        }
         if (ok) {
             float* dst;
             if (a.out_nhwc)
@@ -128,6 +142,14 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const 
                       ((size_t)y * out_w + x) * 8 + 4 * lh;
             *reinterpret_cast<f32x4*>(dst) = v;
         }
+    }
+    if (a.bneck_w) {
+        // the other 16 channels of this pixel live in lane ^ 32
+        dot += __shfl_xor(dot, 32, 64);
+        const float t = dot * a.bneck_scale + a.bneck_shift;
+        if (ok && lh == 0)
+            a.bneck_out[(size_t)frame * a.bneck_frame_stride + (size_t)y * out_w + x] =
+                fmaxf(t, 0.0f);
     }
 }
 
@@ -400,7 +422,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                     for (int nt = 0; nt < NT; ++nt)
                         store_tile(a, out, acc[mt * NT + nt],
                                    cur.ntile * BN + (wn * NT + nt) * 32, lh, y - a.out_y0, x,
-                                   a.W, plane, ok);
+                                   a.W, plane, ok, cur.frame);
                 }
             } else {
                 const int y = cur.ty0 + wm * Cfg::kRowsPerMT + li / TW;

@@ -23,6 +23,8 @@ parity for that, and `finish()` drains the last step.  Everything stays on the
 device; the only host round trip per step is the kept-anchor count of each frame,
 fetched one step after it was produced (the host never waits for the GPU).
 """
+import os
+
 import numpy as np
 
 from dodt_amd import device, ops, synth
@@ -59,7 +61,6 @@ class FramePairPipeline(object):
         # streams: conv stacks of the two nets side by side, per-frame work on its own
         self.img_ctx = device.Context(ctx.device_id)
         n_side = min(self.nf, 2) if side_streams is None else int(side_streams)
-        import os
         hp = os.environ.get('DODT_PIPE_PRIO', '0') == '1'
         self.sides = [device.Context(ctx.device_id, high_priority=hp)
                       for _ in range(max(n_side, 1))]   # tails
@@ -279,9 +280,11 @@ class FramePairPipeline(object):
                                 (3, 3), b['rpn_bev_roi'])
             ops.crop_and_resize(c, bneck_i, (self.img_h, self.img_w, 1), b['img_norm'], A, None,
                                 (3, 3), b['rpn_img_roi'])
+            self._mark(c, st['step'], 'tail%d_crops' % f)
             if computed:
                 self.rpn_head.forward(c, b['rpn_bev_roi'], b['rpn_img_roi'], A, b['rpn_logits'],
                                       b['rpn_offsets'], scratch['rpn'])
+            self._mark(c, st['step'], 'tail%d_rpn' % f)
             # -- a12, a5, a13: decode, project, NMS #1 --------------------------------------
             ops.offset_to_anchor(c, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
             ops.project_anchors_f32(c, b['regressed'], A, None, self.bev_extents_flat, self.p2,
@@ -301,10 +304,12 @@ class FramePairPipeline(object):
             ops.crop_and_resize(c, feat_i, (self.img_h, self.img_w, 32), b['top_img'], self.P,
                                 b['top_count'], (7, 7), b['img_rois'])
             corr_offsets = h.get('corr_offsets') if f % 2 == 0 else None
+            self._mark(c, st['step'], 'tail%d_crops2' % f)
             if computed:
                 self.avod_head.forward(c, b['bev_rois'], b['img_rois'], self.P, b['top_count'],
                                        [b['cls_logits'], b['offsets_4c']], scratch['fc'])
-                if f % 2 == 0:
+                self._mark(c, st['step'], 'tail%d_fc2' % f)
+                if f % 2 == 0 and not os.environ.get('DODT_PIPE_NO_CORR'):
                     # T branch: correlate the pair's BEV features, crop with frame 0's
                     # proposals (dt_rpn_model.py:324-331, dt_avod_model.py:267-273,300-304)
                     feat_b1 = feat['bev_feat'].offset(4 * bev_px * 32 * (f + 1),
@@ -314,6 +319,7 @@ class FramePairPipeline(object):
                     ops.crop_and_resize(c, scratch['corr_map'], (self.bev_h, self.bev_w, CORR_CH),
                                         b['top_bev'], self.P, b['top_count'], (ROI, ROI),
                                         b['corr_rois'])
+                    self._mark(c, st['step'], 'tail%d_corrmap' % f)
                     self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
                                            [b['corr_offsets']], scratch['fc'])
             self._mark(c, st['step'], 'tail%d_heads' % f)
