@@ -248,7 +248,7 @@ int find_layer(dodt_extractor* ex, const char* name) {
 int buffer_for_layer_output(const Layer& l) { return l.dst; }
 
 int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
-               float* override_out, int out_y0, int out_h, float* bneck_out) {
+               float* override_out, int out_y0, int out_h, float* bneck_out, int pool_dst) {
     const KernelVariant& v = variants()[ln.variant];
     const Buffer& src = ex->buf[l.src];
     const Buffer& dst = ex->buf[l.dst];
@@ -281,6 +281,8 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.counter_base = ex->d_counters + 64;
     a.items = ln.d_items;
     a.n_items = ln.n_items;
+    a.pool_out = pool_dst >= 0 ? ex->buf[pool_dst].ptr : nullptr;
+    a.pool_frame_stride = pool_dst >= 0 ? (long long)ex->buf[pool_dst].frame_floats() : 0;
     a.bneck_w = bneck_out ? ex->d_bneck_w : nullptr;
     a.bneck_out = bneck_out;
     a.bneck_scale = ex->bneck_scale;
@@ -308,11 +310,23 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     return DODT_OK;
 }
 
+// a variant's waves hold both rows of every 2x2 pooling window (conv_kernels.h kCanPool)
+bool variant_can_pool(const KernelVariant& v) {
+    const int rows_per_mt = 32 / v.TW, mt = v.MTB / v.WM;
+    return !v.deconv && !v.small_cin && (rows_per_mt >= 2 || mt % 2 == 0) && v.TH % 2 == 0;
+}
+
+bool layer_can_pool(const Layer& l) {
+    return variant_can_pool(variants()[l.main.variant]) &&
+           (l.tail.n_items == 0 || variant_can_pool(variants()[l.tail.variant]));
+}
+
+// pool_dst >= 0: the layer also writes its 2x2 max pool into that buffer
 int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h,
-              float* bneck_out = nullptr) {
-    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h, bneck_out);
+              float* bneck_out = nullptr, int pool_dst = -1) {
+    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h, bneck_out, pool_dst);
     if (rc == DODT_OK && l.tail.n_items > 0)
-        rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h, bneck_out);
+        rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h, bneck_out, pool_dst);
     return rc;
 }
 
@@ -623,12 +637,19 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
     auto L = [&](const char* n) -> const Layer& { return ex->layers[find_layer(ex, n)]; };
 #define RUN(name)                                           \
     if ((rc = run_layer(ex, L(name), nullptr, 0, 0))) return rc;
-    RUN("conv1_1"); RUN("conv1_2");
-    if ((rc = run_pool(ex, CAT1, P1))) return rc;
-    RUN("conv2_1"); RUN("conv2_2");
-    if ((rc = run_pool(ex, CAT2, P2))) return rc;
-    RUN("conv3_1"); RUN("conv3_2"); RUN("conv3_3");
-    if ((rc = run_pool(ex, CAT3, P3))) return rc;
+    // a conv that a 2x2 max pool follows pools in its epilogue when its tiling allows
+    static const bool no_fuse = getenv("DODT_CONV_NO_POOL_FUSE") != nullptr;
+#define RUN_POOLED(name, src, dst)                                                   \
+    if (!no_fuse && layer_can_pool(L(name))) {                                       \
+        if ((rc = run_layer(ex, L(name), nullptr, 0, 0, nullptr, dst))) return rc;   \
+    } else {                                                                         \
+        RUN(name);                                                                   \
+        if ((rc = run_pool(ex, src, dst))) return rc;                                \
+    }
+    RUN("conv1_1"); RUN_POOLED("conv1_2", CAT1, P1);
+    RUN("conv2_1"); RUN_POOLED("conv2_2", CAT2, P2);
+    RUN("conv3_1"); RUN("conv3_2"); RUN_POOLED("conv3_3", CAT3, P3);
+#undef RUN_POOLED
     RUN("conv4_1"); RUN("conv4_2"); RUN("conv4_3");
     RUN("upconv3"); RUN("pyramid_fusion3");
     RUN("upconv2"); RUN("pyramid_fusion2");

@@ -64,6 +64,10 @@ struct ConvArgs {
     int out_nhwc;  // 1: NHWC output (last layer), 0: CB8
     int* counter;  // work-item counter of this launch (zeroed by the host beforehand)
     int* counter_base;  // start of the counter block (words 32.. are diagnostics)
+    // 2x2 max pool fused into the epilogue of the layer a pool follows (conv only, CB8):
+    // pool_out is the pooled map (H/2, W/2, planes from 0), NULL when not fused
+    float* pool_out;
+    long long pool_frame_stride;
     // 1x1 bottleneck fused into the last layer's epilogue (NHWC output, Cout == BN == 32):
     // bneck_out[pixel] = relu(bneck_scale * sum_c bneck_w[c] * y[pixel][c] + bneck_shift)
     const float* bneck_w;          // NULL: no bottleneck
@@ -111,7 +115,9 @@ __device__ __forceinline__ f32x16 mfma32(float w, float x, f32x16 c) {
 
 // Batch-norm + ReLU + store of one 32(channel) x 32(pixel) accumulator tile.
 // Lane (li = pixel, lh): register group g = r>>2 holds channels c0 + 8g + 4lh + (r&3).
-__device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const f32x16& acc,
+// KEEP: the activated values replace the accumulators (for the fused pool).
+template <bool KEEP = false>
+__device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16& acc,
                                            int c0, int lh, int y, int x, int out_w,
                                            long long plane_stride, bool ok, int frame = 0) {
     float dot = 0.0f;   // this lane's 16 channels of the fused 1x1 bottleneck
@@ -125,6 +131,10 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const 
         for (int k = 0; k < 4; ++k) {
             float t = acc[4 * g + k] * sc[k] + sh[k];
             v[k] = a.relu ? fmaxf(t, 0.0f) : t;
+        }
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * g + k] = v[k];
         }
         if (a.bneck_w) {
             const f32x4 bw = *reinterpret_cast<const f32x4*>(a.bneck_w + c);
@@ -150,6 +160,32 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, const 
         if (ok && lh == 0)
             a.bneck_out[(size_t)frame * a.bneck_frame_stride + (size_t)y * out_w + x] =
                 fmaxf(t, 0.0f);
+    }
+}
+
+// 2x2/2 max pool of one activated 32(channel) x 32(pixel) tile: the horizontal neighbour
+// is lane ^ 1, the vertical one lane ^ TW (two or more rows per 32-pixel tile) or the same
+// lane of the next row's tile (`below`, TW == 32).  Lanes at even (y, x) store.
+template <int TW>
+__device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, const f32x16& below,
+                                          int c0, int lh, int y, int x, int frame, bool ok) {
+    const int OW = a.W >> 1;
+    const long long plane = (long long)(a.H >> 1) * OW * 8;
+    float* base = a.pool_out + (size_t)frame * a.pool_frame_stride +
+                  ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
+    const bool writer = ok && !(y & 1) && !(x & 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = v[4 * g + k];
+            if constexpr (TW < 32) t = fmaxf(t, __shfl_xor(t, TW, 64));
+            else t = fmaxf(t, below[4 * g + k]);
+            m[k] = fmaxf(t, __shfl_xor(t, 1, 64));
+        }
+        if (writer)
+            *reinterpret_cast<f32x4*>(base + (size_t)((c0 + 8 * g + 4 * lh) >> 3) * plane) = m;
     }
 }
 
@@ -413,16 +449,41 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             if constexpr (!DECONV) {
                 const int out_rows = a.H - a.out_y0;
                 const long long plane = (long long)out_rows * a.W * 8;
+                // pooling in registers needs both rows of a 2x2 window in this wave
+                constexpr bool kCanPool = Cfg::kRowsPerMT >= 2 || MT % 2 == 0;
+                const bool pool = kCanPool && a.pool_out != nullptr;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int y = cur.ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
                     const int x = cur.tx0 + li % TW;
                     const bool ok = st && y < a.H && x < a.W && y >= a.out_y0;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        store_tile(a, out, acc[mt * NT + nt],
-                                   cur.ntile * BN + (wn * NT + nt) * 32, lh, y - a.out_y0, x,
-                                   a.W, plane, ok, cur.frame);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (pool)
+                            store_tile<true>(a, out, acc[mt * NT + nt],
+                                             cur.ntile * BN + (wn * NT + nt) * 32, lh,
+                                             y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                        else
+                            store_tile<false>(a, out, acc[mt * NT + nt],
+                                              cur.ntile * BN + (wn * NT + nt) * 32, lh,
+                                              y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                    }
+                }
+                if constexpr (kCanPool) {
+                    if (pool) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt += (Cfg::kRowsPerMT >= 2 ? 1 : 2)) {
+                            const int y = cur.ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
+                            const int x = cur.tx0 + li % TW;
+                            const bool ok = st && y < a.H && x < a.W;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                pool_tile<TW>(a, acc[mt * NT + nt],
+                                              acc[(Cfg::kRowsPerMT >= 2 ? mt : mt + 1) * NT + nt],
+                                              cur.ntile * BN + (wn * NT + nt) * 32, lh, y, x,
+                                              cur.frame, ok);
+                        }
+                    }
                 }
             } else {
                 const int y = cur.ty0 + wm * Cfg::kRowsPerMT + li / TW;
