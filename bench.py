@@ -192,8 +192,17 @@ def main():
     flops = pipe.flops_per_step()
     achieved = flops / (conv_ms * 1e-3) / 1e12
     peak = 157.3      # TFLOP/s, fp32 MFMA, MI355X_MICROARCH.md chip table
+    # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
+    # figure comes from the rocprofv3 --pmc passes over this same command (profiles/)
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, 'profiles', 'r1_conv_traffic.json')
+    if os.path.exists(tj):
+        t = json.load(open(tj))
+        traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
+        traffic_src = t['source']
     roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                    frac=round(achieved / peak, 4), traffic=None,
+                    frac=round(achieved / peak, 4), traffic=traffic, traffic_unit='bytes/launch',
+                    traffic_source=traffic_src,
                     kernel='conv3x3_mfma_kernel (30 launches per step) + 2 first-layer launches',
                     launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
                     launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),

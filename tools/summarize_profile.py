@@ -95,6 +95,13 @@ if traffic:
     for k, (tot, n) in traffic.items():
         lines.append('- %s: %.1f MB over %d conv dispatches = %.2f MB per dispatch' % (
             k, tot / 1e6, n, tot / 1e6 / max(n, 1)))
+if len(traffic) == 2:
+    per = {k: tot / max(n, 1) for k, (tot, n) in traffic.items()}
+    json.dump({'kernel': 'conv3x3_* (all conv launches of the timed steps)',
+               'fetch_bytes_per_launch': per['fetch'], 'write_bytes_per_launch': per['write'],
+               'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 '
+                         '(gfx950 correction), profiles/%s_summary.md' % tag},
+              open(os.path.join(out, '%s_conv_traffic.json' % tag), 'w'), indent=1)
 bj = os.path.join(root, 'gpurun_out', '%s_bench.json' % tag)
 if os.path.exists(bj):
     txt = [l for l in open(bj) if l.startswith('{')]
