@@ -105,6 +105,9 @@ const std::vector<KernelVariant>& variants() {
         Inst<16, 4, 4, 1, 32, true>::variant(),
         Inst<8, 4, 4, 1, 32, true>::variant(),
         Inst<4, 4, 4, 1, 32, true>::variant(),
+        Inst<16, 4, 4, 1, 64, true>::variant(),
+        Inst<8, 4, 4, 1, 64, true>::variant(),
+        Inst<4, 4, 4, 1, 64, true>::variant(),
     };
     return v;
 }
@@ -118,6 +121,8 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
         if (v.deconv != deconv || v.small_cin != small || v.tail_only || Cout % v.BN != 0) continue;
+        static const int max_bn = getenv("DODT_CONV_MAX_BN") ? atoi(getenv("DODT_CONV_MAX_BN")) : 1024;
+        if (v.BN > max_bn) continue;
         // the chunk pipeline needs >= 4 chunks of 8 channels per work item
         if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0 || Cin < 32)) continue;
         const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;

@@ -99,13 +99,13 @@ struct ConvCfg {
     static constexpr int NW = (kWItems + 255) / 256;
     // accumulator registers per lane and the residency they allow (unified 512-entry
     // VGPR+AGPR file per SIMD): ask the register allocator for that many waves
-    static constexpr int kAccRegs = (DECONV ? 4 : MT * NT) * 16;
+    static constexpr int kAccRegs = (DECONV ? 4 * NT : MT * NT) * 16;
     // persistent workgroups hide their own prologue/epilogue, so two per CU suffice:
     // give the register allocator the full 256-register budget of 2 waves per SIMD
     static constexpr int kMinWaves = 2;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MTB % WM == 0 && (BN / 32) % WN == 0, "tile split");
-    static_assert(!DECONV || (MT == 1 && NT == 1), "deconv: one M x N tile per wave");
+    static_assert(!DECONV || MT == 1, "deconv: one 32-pixel tile per wave (x 4 parity classes)");
 };
 
 // D[row = output channel][col = pixel] += W[channel][k] * X[k][pixel]
@@ -196,7 +196,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
     constexpr int PW = Cfg::PW;
     constexpr int MT = Cfg::MT, NT = Cfg::NT, NP = Cfg::NP, NW = Cfg::NW;
-    constexpr int NACC = DECONV ? 4 : MT * NT;
+    constexpr int NACC = DECONV ? 4 * NT : MT * NT;
     constexpr int PS = kPixStride;
     constexpr int NSLOT = NP + NW;            // staging registers (float4) per thread
     constexpr int SPT = (NSLOT + 8) / 9;      // staging slots handled per tap
@@ -407,34 +407,48 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         } else {
             // patch origin is (ty0-1, tx0-1): in[i][j] sits at patch (r+1, c+1)
             const float* pa = bP + x_base;
-            const f32x4 a00 = *reinterpret_cast<const f32x4*>(pa + (PW + 1) * PS);  // in[i][j]
-            const f32x4 a10 = *reinterpret_cast<const f32x4*>(pa + 1 * PS);         // in[i-1][j]
-            const f32x4 a01 = *reinterpret_cast<const f32x4*>(pa + PW * PS);        // in[i][j-1]
-            const f32x4 a11 = *reinterpret_cast<const f32x4*>(pa);                  // in[i-1][j-1]
-            f32x4 bw[9];
+            f32x4 af[4];
+            af[0] = *reinterpret_cast<const f32x4*>(pa + (PW + 1) * PS);  // in[i][j]
+            af[1] = *reinterpret_cast<const f32x4*>(pa + 1 * PS);         // in[i-1][j]
+            af[2] = *reinterpret_cast<const f32x4*>(pa + PW * PS);        // in[i][j-1]
+            af[3] = *reinterpret_cast<const f32x4*>(pa);                  // in[i-1][j-1]
+            // taps ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj] * w[ky][kx]: every
+            // tap feeds one output-parity class from one of the four input pixels.  Order:
+            // classes alternate so that consecutive taps use different accumulators.
+            f32x4 bw[2][NT];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                bw[tap] = *reinterpret_cast<const f32x4*>(bW + w_base + tap * 2 * BN * 4);
-            __builtin_amdgcn_sched_barrier(0);
-            // taps ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj] * w[ky][kx]
-#define DODT_DECONV_S(S, STAGE_A, STAGE_B)                                                    \
-            acc[0] = mfma32(bw[0][S], a00[S], acc[0]);                                        \
-            acc[1] = mfma32(bw[1][S], a00[S], acc[1]);                                        \
-            acc[2] = mfma32(bw[3][S], a00[S], acc[2]);                                        \
-            acc[3] = mfma32(bw[4][S], a00[S], acc[3]);                                        \
-            STAGE_A                                                                           \
-            acc[0] = mfma32(bw[6][S], a10[S], acc[0]);                                        \
-            acc[1] = mfma32(bw[7][S], a10[S], acc[1]);                                        \
-            acc[2] = mfma32(bw[5][S], a01[S], acc[2]);                                        \
-            STAGE_B                                                                           \
-            acc[0] = mfma32(bw[2][S], a01[S], acc[0]);                                        \
-            acc[0] = mfma32(bw[8][S], a11[S], acc[0]);
-            DODT_DECONV_S(0, DODT_STAGE_TAP(0), DODT_STAGE_TAP(1))
-            DODT_DECONV_S(1, DODT_STAGE_TAP(2), DODT_STAGE_TAP(3))
-            DODT_DECONV_S(2, DODT_STAGE_TAP(4), DODT_STAGE_TAP(5))
-            DODT_DECONV_S(3, DODT_STAGE_TAP(6), DODT_STAGE_TAP(7))
-            DODT_STAGE_TAP(8)
-            __builtin_amdgcn_sched_barrier(0);
+            for (int nt = 0; nt < NT; ++nt)
+                bw[0][nt] = *reinterpret_cast<const f32x4*>(bW + w_base + nt * 128);   // tap 0
+#define DODT_DTAP(I, TAP, CLS, AF, NEXT_TAP)                                                  \
+            {                                                                                 \
+                constexpr int cb = (I) & 1, nb = cb ^ 1;                                      \
+                if constexpr ((NEXT_TAP) >= 0) {                                              \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                        bw[nb][nt] = *reinterpret_cast<const f32x4*>(                         \
+                            bW + w_base + (NEXT_TAP) * 2 * BN * 4 + nt * 128);                \
+                }                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                            \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                        acc[(CLS) * NT + nt] =                                                \
+                            mfma32(bw[cb][nt][s], af[AF][s], acc[(CLS) * NT + nt]);           \
+                DODT_STAGE_TAP(I)                                                             \
+                _Pragma("unroll") for (int s = 2; s < 4; ++s)                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                        acc[(CLS) * NT + nt] =                                                \
+                            mfma32(bw[cb][nt][s], af[AF][s], acc[(CLS) * NT + nt]);           \
+                __builtin_amdgcn_sched_barrier(0);                                            \
+            }
+            //        step tap class input  next tap
+            DODT_DTAP(0, 0, 0, 0, 1)
+            DODT_DTAP(1, 1, 1, 0, 3)
+            DODT_DTAP(2, 3, 2, 0, 4)
+            DODT_DTAP(3, 4, 3, 0, 6)
+            DODT_DTAP(4, 6, 0, 1, 7)
+            DODT_DTAP(5, 7, 1, 1, 5)
+            DODT_DTAP(6, 5, 2, 2, 2)
+            DODT_DTAP(7, 2, 0, 2, 8)
+            DODT_DTAP(8, 8, 0, 3, -1)
         }
         if (more) {
             ok_regs = ok_issue;       // pre[] now holds (load_item, ld_ch)
@@ -492,8 +506,11 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                 const long long plane = (long long)(2 * a.H) * (2 * a.W) * 8;
 #pragma unroll
                 for (int cls = 0; cls < 4; ++cls)
-                    store_tile(a, out, acc[cls], cur.ntile * BN + wn * 32, lh,
-                               2 * y + (cls >> 1), 2 * x + (cls & 1), 2 * a.W, plane, ok);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        store_tile(a, out, acc[cls * NT + nt],
+                                   cur.ntile * BN + (wn * NT + nt) * 32, lh, 2 * y + (cls >> 1),
+                                   2 * x + (cls & 1), 2 * a.W, plane, ok);
             }
 #pragma unroll
             for (int k = 0; k < NACC; ++k)
@@ -524,7 +541,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #undef DODT_TAP
 #undef DODT_STAGE_ONE
 #undef DODT_STAGE_TAP
-#undef DODT_DECONV_S
+#undef DODT_DTAP
 }
 
 // ---------------------------------------------------------------------------

@@ -24,13 +24,21 @@ def is_tail(r):          # quarter-size tiles of a tail launch: <TW, 4, 4, 1, 32
 
 
 for label, layers, start in (('BEV', BEV, bev_idx[-1]), ('IMG', IMG, img_idx[-1])):
+    convs = [(n, g) for n, g in layers if g]          # pools / bottleneck may be fused away
     tot = 0.0
     k = start
     t_first = int(rows[start]['Start_Timestamp'])
-    for nm, gf in layers:
+    ci = 0
+    while ci < len(convs) and k < len(rows):
         r = rows[k]
         d = dur(r)
         k += 1
+        if 'conv3x3' not in r['Kernel_Name']:
+            tot += d
+            print('%s %-8s %-26s %8.1f us' % (label, '', r['Kernel_Name'][23:49], d))
+            continue
+        nm, gf = convs[ci]
+        ci += 1
         tail = ''
         if k < len(rows) and is_tail(rows[k]):
             gap = (int(rows[k]['Start_Timestamp']) - int(r['End_Timestamp'])) / 1e3
