@@ -15,6 +15,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 PTS_VELO_XYZI, PTS_CAM_3XN = 0, 1
 EXTRACTOR_VGG_PYR = 0
 EXTRACTOR_SHARED_GPU = 0x100
+EXTRACTOR_BF16 = 0x200
 
 
 class DodtError(RuntimeError):

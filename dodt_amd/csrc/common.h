@@ -1,6 +1,8 @@
 // Internal declarations shared by the HIP translation units of libdodt_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
 
 #include <cstdarg>
 #include <cstdint>
@@ -42,6 +44,20 @@ struct Scratch {
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// bf16 <-> float on the host: round to nearest even, like the device's v_cvt_pk_bf16_f32
+static inline uint16_t float_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace dodt

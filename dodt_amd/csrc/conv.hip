@@ -19,67 +19,16 @@
 
 #include "common.h"
 #include "conv_kernels.h"
+#include "conv_variants.h"
 
 namespace {
 
 using dodt::ConvArgs;
 
-// ---------------------------------------------------------------------------
-// kernel instantiations
-// ---------------------------------------------------------------------------
-struct KernelVariant {
-    int TW, MTB, WM, WN, BN, CK;
-    bool deconv, small_cin;
-    int TH, lds_bytes;
-    int blocks_per_cu;  // resident workgroups per CU (registers and LDS permitting)
-    void (*launch)(const ConvArgs&, dim3 grid, hipStream_t s);
-    hipError_t (*prepare)();
-    bool tail_only = false;  // quarter-size tiles: never a layer's main variant
-};
-
-KernelVariant tail_only(KernelVariant v) {
-    v.tail_only = true;
-    return v;
-}
-
-template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
-struct Inst {
-    using Cfg = dodt::ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
-    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL((dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV>), grid,
-                           dim3(256), Cfg::kLdsBytes, s, a);
-    }
-    static hipError_t prepare() {
-        return hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&dodt::conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
-    }
-    static KernelVariant variant() {
-        int per_cu = Cfg::kMinWaves;  // one wave of each workgroup per SIMD
-        const int by_lds = (160 * 1024) / Cfg::kLdsBytes;
-        if (per_cu > by_lds) per_cu = by_lds;
-        return KernelVariant{TW, MTB, WM, WN, BN, dodt::kCK, DECONV, false, Cfg::TH,
-                             Cfg::kLdsBytes, per_cu, &launch, &prepare};
-    }
-};
-
-template <int TW, int MTB, int CK>
-struct InstSmall {
-    using Cfg = dodt::SmallCfg<TW, MTB, CK>;
-    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL((dodt::conv3x3_small_cin_kernel<TW, MTB, CK>), grid, dim3(256),
-                           Cfg::kLdsBytes, s, a);
-    }
-    static hipError_t prepare() {
-        return hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&dodt::conv3x3_small_cin_kernel<TW, MTB, CK>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
-    }
-    static KernelVariant variant() {
-        return KernelVariant{TW, MTB, 4, 1, 32, CK, false, true, Cfg::TH, Cfg::kLdsBytes, 4,
-                             &launch, &prepare};
-    }
-};
+using dodt::KernelVariant;
+using dodt::Inst;
+using dodt::InstSmall;
+using dodt::tail_only;
 
 const std::vector<KernelVariant>& variants() {
     static const std::vector<KernelVariant> v = {
@@ -109,21 +58,28 @@ const std::vector<KernelVariant>& variants() {
         Inst<8, 4, 4, 1, 64, true>::variant(),
         Inst<4, 4, 4, 1, 64, true>::variant(),
     };
-    return v;
+    static const std::vector<KernelVariant> all = [] {
+        std::vector<KernelVariant> a = v;
+        for (const KernelVariant& b : dodt::bf16_variants()) a.push_back(b);
+        return a;
+    }();
+    return all;
 }
 
 // smallest padded pixel count wins; ties go to the larger output tile
-int pick_variant(bool deconv, int H, int W, int Cin, int Cout) {
+int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16) {
     const auto& vs = variants();
     const bool small = Cin < dodt::kCK;
     int best = -1;
     double best_cost = 1e300;
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
-        if (v.deconv != deconv || v.small_cin != small || v.tail_only || Cout % v.BN != 0) continue;
+        if (v.deconv != deconv || v.small_cin != small || v.tail_only || v.bf16 != bf16 ||
+            Cout % v.BN != 0)
+            continue;
         static const int max_bn = getenv("DODT_CONV_MAX_BN") ? atoi(getenv("DODT_CONV_MAX_BN")) : 1024;
         if (v.BN > max_bn) continue;
-        // the chunk pipeline needs >= 4 chunks of 8 channels per work item
+        // the chunk pipeline needs >= 2 chunks (8 channels fp32, 16 channels bf16) per item
         if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0 || Cin < 32)) continue;
         const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;
         // mild preference for more work per staged byte
@@ -200,7 +156,8 @@ copy_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long 
 struct Buffer {
     int H = 0, W = 0, C = 0;
     float* ptr = nullptr;
-    size_t frame_floats() const { return (size_t)H * W * C; }
+    bool bf16 = false;   // CB16 bf16 map (2 bytes per element) instead of CB8 / NHWC fp32
+    size_t frame_floats() const { return (size_t)H * W * C / (bf16 ? 2 : 1); }
 };
 
 // one kernel launch of a layer: a variant and the work items it walks
@@ -232,6 +189,7 @@ enum Buf { X0, C1A, CAT1, P1, C2A, CAT2, P2, C3A, C3B, CAT3, P3, C4A, C4B, C4C, 
 struct dodt_extractor {
     dodt_ctx* ctx = nullptr;
     int in_h = 0, in_w = 0, in_c = 0, pad_top = 0, batch = 0;
+    bool bf16 = false;  // conv path on bf16 MFMA (fp32 accumulate, fp32 BN/ReLU, bf16 maps)
     int H = 0, W = 0;  // padded input size
     Buffer buf[NBUF];
     std::vector<Layer> layers;
@@ -417,8 +375,10 @@ extern "C" {
 int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c, int pad_top,
                           int batch, dodt_extractor** out) {
     DODT_REQUIRE(ctx && out, "dodt_extractor_create: NULL argument");
-    const bool shared_gpu = (kind & DODT_EXTRACTOR_SHARED_GPU) != 0;
-    kind &= ~DODT_EXTRACTOR_SHARED_GPU;
+    const bool bf16 = (kind & DODT_EXTRACTOR_BF16) != 0;
+    // (the bf16 kernels have no quarter-size instantiations: single launches)
+    const bool shared_gpu = (kind & DODT_EXTRACTOR_SHARED_GPU) != 0 || bf16;
+    kind &= ~(DODT_EXTRACTOR_SHARED_GPU | DODT_EXTRACTOR_BF16);
     DODT_REQUIRE(kind == DODT_EXTRACTOR_VGG_PYR, "dodt_extractor_create: unknown kind %d", kind);
     DODT_REQUIRE(in_h > 0 && in_w > 0 && in_c >= 2 && in_c % 2 == 0 && pad_top >= 0 && batch >= 1,
                  "dodt_extractor_create: bad sizes (in_c must be even)");
@@ -432,6 +392,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     ex->ctx = ctx;
     ex->in_h = in_h; ex->in_w = in_w; ex->in_c = in_c; ex->pad_top = pad_top; ex->batch = batch;
     ex->H = H; ex->W = W;
+    ex->bf16 = bf16;
     auto setb = [&](int id, int h, int w, int c) { ex->buf[id].H = h; ex->buf[id].W = w; ex->buf[id].C = c; };
     setb(X0, H, W, in_c);
     setb(C1A, H, W, 32); setb(CAT1, H, W, 64); setb(P1, H / 2, W / 2, 32);
@@ -440,6 +401,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     setb(P3, H / 8, W / 8, 128);
     setb(C4A, H / 8, W / 8, 256); setb(C4B, H / 8, W / 8, 256); setb(C4C, H / 8, W / 8, 256);
     setb(F3, H / 4, W / 4, 64); setb(F2, H / 2, W / 2, 32); setb(F1, H, W, 32);
+    for (int i = 0; i < NBUF; ++i) ex->buf[i].bf16 = bf16 && i != X0 && i != F1;
     for (int i = 0; i < NBUF; ++i) {
         if (i == F1) continue;  // the last layer writes into the caller's buffer
         const size_t bytes = ex->buf[i].frame_floats() * batch * sizeof(float);
@@ -461,7 +423,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         Layer l;
         l.name = name; l.deconv = deconv; l.H = h; l.W = w; l.Cin = cin; l.Cout = cout;
         l.src = src; l.src_coff = src_coff; l.dst = dst; l.dst_coff = dst_coff;
-        l.variant = pick_variant(deconv, h, w, cin, cout);
+        l.variant = pick_variant(deconv, h, w, cin, cout, bf16);
         l.real_cin = cin;
         ex->layers.push_back(l);
     };
@@ -571,20 +533,32 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     }
     const KernelVariant& v = variants()[ln->variant];
     const int nchunks = l.Cin / v.CK;
+    // fp32 kernels: floats; bf16 MFMA kernels: bf16 pairs packed in the same array (half of it)
     std::vector<float> blocked((size_t)9 * l.Cin * l.Cout, 0.0f);
+    uint16_t* blocked16 = reinterpret_cast<uint16_t*>(blocked.data());
+    const bool w16 = v.bf16 && !v.small_cin;
     for (int tap = 0; tap < 9; ++tap)
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co) {
                 const float val = l.deconv ? w[((size_t)tap * cout + co) * cin + ci]
                                            : w[((size_t)tap * cin + ci) * cout + co];
-                const int nt = co / v.BN, n = co % v.BN, ch = ci / v.CK, c = ci % v.CK;
-                size_t idx;
-                if (v.small_cin)   // [tap][c][n]
-                    idx = ((size_t)tap * v.CK + c) * v.BN + n;
-                else               // [n_tile][chunk][tap][h = c/4][n][s = c%4]
-                    idx = (((((size_t)nt * nchunks + ch) * 9 + tap) * 2 + c / 4) * v.BN + n) * 4 +
-                          c % 4;
-                blocked[idx] = val;
+                int n = co % v.BN;
+                if (v.bf16) {
+                    // MFMA row that delivers channel co (conv_kernels.h group_channel<PERM>):
+                    // channel 16a + 8lh + 4b + k  <-  row 8(2a + b) + 4lh + k
+                    const int c32 = co % 32, a2 = c32 >> 4, lh = (c32 >> 3) & 1, b2 = (c32 >> 2) & 1;
+                    n = (n / 32) * 32 + 8 * (2 * a2 + b2) + 4 * lh + (c32 & 3);
+                }
+                const int nt = co / v.BN, ch = ci / v.CK, c = ci % v.CK;
+                if (v.small_cin) {   // [tap][c][n]
+                    blocked[((size_t)tap * v.CK + c) * v.BN + n] = val;
+                } else if (!w16) {   // [n_tile][chunk][tap][h = c/4][n][s = c%4]
+                    blocked[(((((size_t)nt * nchunks + ch) * 9 + tap) * 2 + c / 4) * v.BN + n) * 4 +
+                            c % 4] = val;
+                } else {             // [n_tile][chunk16][tap][h = c/8][n][j = c%8] bf16
+                    blocked16[(((((size_t)nt * nchunks + ch) * 9 + tap) * 2 + c / 8) * v.BN + n) * 8 +
+                              c % 8] = dodt::float_to_bf16(val);
+                }
             }
     if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, blocked.size() * sizeof(float)));
     DODT_HIP_CHECK(hipMemcpyAsync(ln->d_w, blocked.data(), blocked.size() * sizeof(float),
@@ -651,6 +625,10 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
         RUN(name);                                                                   \
         if ((rc = run_pool(ex, src, dst))) return rc;                                \
     }
+    if (ex->bf16)   // there is no stand-alone pool kernel for bf16 maps
+        for (const char* n : {"conv1_2", "conv2_2", "conv3_3"})
+            DODT_REQUIRE(!no_fuse && layer_can_pool(L(n)),
+                         "bf16 extractor: layer %s cannot pool in its epilogue", n);
     RUN("conv1_1"); RUN_POOLED("conv1_2", CAT1, P1);
     RUN("conv2_1"); RUN_POOLED("conv2_2", CAT2, P2);
     RUN("conv3_1"); RUN("conv3_2"); RUN_POOLED("conv3_3", CAT3, P3);
@@ -692,20 +670,24 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
     if (w) *w = ow;
     if (c) *c = l.Cout;
     if (!dst) return DODT_OK;
-    // CB8 planes [dst_coff/8, +Cout/8) of every frame -> dense NHWC host tensor
+    // CB8 fp32 (or CB16 bf16) planes of every frame -> dense NHWC fp32 host tensor
     DODT_HIP_CHECK(hipStreamSynchronize(ex->ctx->stream));
-    const size_t plane = (size_t)oh * ow * 8;
-    const int planes = l.Cout / 8;
+    const int pc = b.bf16 ? 16 : 8;                 // channels per plane
+    const size_t plane = (size_t)oh * ow * 8;       // floats per plane, both layouts
+    const int planes = l.Cout / pc;
     std::vector<float> tmp(plane * planes);
+    const uint16_t* tmp16 = reinterpret_cast<const uint16_t*>(tmp.data());
     for (int f = 0; f < ex->batch; ++f) {
         DODT_HIP_CHECK(hipMemcpy(tmp.data(),
-                                 b.ptr + (size_t)f * b.frame_floats() + (size_t)(l.dst_coff / 8) * plane,
+                                 b.ptr + (size_t)f * b.frame_floats() + (size_t)(l.dst_coff / pc) * plane,
                                  tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
         float* o = dst + (size_t)f * oh * ow * l.Cout;
         for (int pl = 0; pl < planes; ++pl)
             for (size_t px = 0; px < (size_t)oh * ow; ++px)
-                for (int k = 0; k < 8; ++k)
-                    o[px * l.Cout + pl * 8 + k] = tmp[pl * plane + px * 8 + k];
+                for (int k = 0; k < pc; ++k)
+                    o[px * l.Cout + pl * pc + k] =
+                        b.bf16 ? dodt::bf16_to_float(tmp16[(pl * plane + px * 8) * 2 + k])
+                               : tmp[pl * plane + px * 8 + k];
     }
     return DODT_OK;
 }

@@ -1,0 +1,33 @@
+// bf16 instantiations of the conv kernels (separate translation unit: they compile in
+// parallel with the fp32 ones).  Same tilings as conv.hip's main variants.
+#include "common.h"
+#include "conv_variants.h"
+
+namespace dodt {
+
+std::vector<KernelVariant> bf16_variants() {
+    return {
+        InstSmall<32, 16, 6, true>::variant(),
+        InstSmall<16, 12, 4, true>::variant(),
+        InstSmall<16, 16, 6, true>::variant(),
+        InstSmall<16, 16, 4, true>::variant(),
+        Inst<32, 16, 4, 1, 32, false, true>::variant(),
+        Inst<16, 16, 4, 1, 32, false, true>::variant(),
+        Inst<16, 8, 4, 1, 64, false, true>::variant(),
+        Inst<16, 12, 4, 1, 32, false, true>::variant(),
+        Inst<8, 8, 4, 1, 32, false, true>::variant(),
+        Inst<8, 8, 4, 1, 64, false, true>::variant(),
+        Inst<8, 4, 2, 2, 128, false, true>::variant(),
+        Inst<8, 4, 4, 1, 64, false, true>::variant(),
+        Inst<4, 4, 2, 2, 128, false, true>::variant(),
+        Inst<4, 4, 4, 1, 64, false, true>::variant(),
+        Inst<16, 4, 4, 1, 32, true, true>::variant(),
+        Inst<8, 4, 4, 1, 32, true, true>::variant(),
+        Inst<4, 4, 4, 1, 32, true, true>::variant(),
+        Inst<16, 4, 4, 1, 64, true, true>::variant(),
+        Inst<8, 4, 4, 1, 64, true, true>::variant(),
+        Inst<4, 4, 4, 1, 64, true, true>::variant(),
+    };
+}
+
+}  // namespace dodt

@@ -113,17 +113,42 @@ __device__ __forceinline__ f32x16 mfma32(float w, float x, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, c, 0, 0, 0);
 }
 
+// bf16 path: one v_mfma_f32_32x32x16_bf16 takes the 8 + 8 channels that the fp32 path walks
+// in four k-steps; the operands are the same 16-byte LDS reads (8 bf16 instead of 4 floats)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mfma_bf16(f32x4 w, f32x4 x, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w),
+                                                   __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+// two floats -> two bf16 (round to nearest even) in one register
+__device__ __forceinline__ float pack_bf16(float lo, float hi) {
+    return __builtin_bit_cast(float, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// Channel of accumulator register group g (4 consecutive channels) of lane half lh inside a
+// 32-channel tile.  fp32 kernels: MFMA row order, 8g + 4lh.  bf16 kernels (PERM): the host
+// permutes the weight rows so that a lane's 16 channels are two runs of 8 consecutive ones
+// (16(g>>1) + 8lh + 4(g&1)): two 16-byte bf16 stores per lane.
+template <bool PERM>
+__device__ __forceinline__ int group_channel(int g, int lh) {
+    return PERM ? 16 * (g >> 1) + 8 * lh + 4 * (g & 1) : 8 * g + 4 * lh;
+}
+
 // Batch-norm + ReLU + store of one 32(channel) x 32(pixel) accumulator tile.
 // Lane (li = pixel, lh): register group g = r>>2 holds channels c0 + 8g + 4lh + (r&3).
 // KEEP: the activated values replace the accumulators (for the fused pool).
-template <bool KEEP = false>
+// PERM: channel order of bf16 kernels; OUT16: store bf16 into a CB16 map (needs PERM).
+template <bool KEEP = false, bool PERM = false, bool OUT16 = false>
 __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16& acc,
                                            int c0, int lh, int y, int x, int out_w,
                                            long long plane_stride, bool ok, int frame = 0) {
+    static_assert(!OUT16 || PERM, "bf16 output needs the permuted channel order");
     float dot = 0.0f;   // this lane's 16 channels of the fused 1x1 bottleneck
+    f32x2 half = {0.f, 0.f};   // OUT16: the even group's four channels, packed
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int c = c0 + 8 * g + 4 * lh;
+        const int c = c0 + group_channel<PERM>(g, lh);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
         f32x4 v;
@@ -143,7 +168,17 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16
             dot += v[2] * bw[2];
             dot += v[3] * bw[3];
         }
-        if (ok) {
+        if constexpr (OUT16) {
+            // groups (0,1) and (2,3) are 8 consecutive channels each: one 16-byte store
+            if (!(g & 1)) {
+                half = f32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            } else if (ok) {
+                float* dst = out + (size_t)((a.out_coff + c) >> 4) * plane_stride +
+                             ((size_t)y * out_w + x) * 8 + 4 * lh;
+                *reinterpret_cast<f32x4*>(dst) =
+                    f32x4{half[0], half[1], pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            }
+        } else if (ok) {
             float* dst;
             if (a.out_nhwc)
                 dst = out + ((size_t)y * out_w + x) * a.out_ld + a.out_coff + c;
@@ -166,7 +201,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16
 // 2x2/2 max pool of one activated 32(channel) x 32(pixel) tile: the horizontal neighbour
 // is lane ^ 1, the vertical one lane ^ TW (two or more rows per 32-pixel tile) or the same
 // lane of the next row's tile (`below`, TW == 32).  Lanes at even (y, x) store.
-template <int TW>
+template <int TW, bool PERM = false, bool OUT16 = false>
 __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, const f32x16& below,
                                           int c0, int lh, int y, int x, int frame, bool ok) {
     const int OW = a.W >> 1;
@@ -174,6 +209,7 @@ __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, co
     float* base = a.pool_out + (size_t)frame * a.pool_frame_stride +
                   ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
     const bool writer = ok && !(y & 1) && !(x & 1);
+    f32x2 half = {0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 m;
@@ -184,12 +220,22 @@ __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, co
             else t = fmaxf(t, below[4 * g + k]);
             m[k] = fmaxf(t, __shfl_xor(t, 1, 64));
         }
-        if (writer)
-            *reinterpret_cast<f32x4*>(base + (size_t)((c0 + 8 * g + 4 * lh) >> 3) * plane) = m;
+        const int c = c0 + group_channel<PERM>(g, lh);
+        if constexpr (OUT16) {
+            if (!(g & 1))
+                half = f32x2{pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3])};
+            else if (writer)
+                *reinterpret_cast<f32x4*>(base + (size_t)(c >> 4) * plane) =
+                    f32x4{half[0], half[1], pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3])};
+        } else if (writer) {
+            *reinterpret_cast<f32x4*>(base + (size_t)(c >> 3) * plane) = m;
+        }
     }
 }
 
-template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
+// BF16: activations are CB16 bf16 maps (32 bytes per pixel and plane, like CB8 fp32: all
+// staging below is byte-identical), a K chunk is 16 channels and one MFMA per tap and tile.
+template <int TW, int MTB, int WM, int WN, int BN, bool DECONV, bool BF16 = false>
 __global__ void
 __launch_bounds__(256, (ConvCfg<TW, MTB, WM, WN, BN, DECONV>::kMinWaves))
 conv3x3_mfma_kernel(const ConvArgs a) {
@@ -210,7 +256,8 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int nchunks = a.Cin / kCK;
+    constexpr int kChunkCh = BF16 ? 16 : 8;   // channels per K chunk = one plane
+    const int nchunks = a.Cin / kChunkCh;
     const int in_plane = a.H * a.W * 8;  // floats per input plane
 
     // Persistent workgroup.  Work item = (frame, n-tile, spatial tile), listed by the host
@@ -245,7 +292,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             ok_issue |= (ok ? 1u : 0u) << k;
         }
         in_item = a.in + (size_t)it.frame * a.in_frame_stride +
-                  (size_t)(a.in_coff >> 3) * in_plane;
+                  (size_t)(a.in_coff / kChunkCh) * in_plane;
         w_item = reinterpret_cast<const f32x4*>(a.w + (size_t)it.ntile * nchunks * Cfg::kWFloats);
     };
     f32x4 pre[NSLOT];
@@ -298,10 +345,11 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         dbg_r0 = __builtin_amdgcn_s_memrealtime();
     }
     int load_item = comp_item, load_ch = 0;    // chunk whose loads are issued next
-    int next_item = a.n_items;                 // successor of comp_item (from the counter);
-                                               // fetched during an item's first step and not
-                                               // needed before its chunk nchunks-2 (host
-                                               // guarantees nchunks >= 4)
+    // the two items after comp_item (from the counter): q0 is fetched before the prologue's
+    // barrier, after that the item behind q0 is fetched during every item's first step.  The
+    // load pointer runs two chunks ahead, i.e. at most one item ahead (host: nchunks >= 2).
+    int q0 = a.n_items, q1 = a.n_items;
+    if (tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
     setup_loads(decode(load_item));
     unsigned ok_regs = ok_issue;               // mask of the data sitting in pre[]
     // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
@@ -309,7 +357,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     {                                                                                         \
         if (++load_ch == nchunks) {                                                           \
             load_ch = 0;                                                                      \
-            load_item = next_item;                                                            \
+            load_item = (load_item == comp_item) ? q0 : q1;                                   \
             if (load_item < a.n_items) setup_loads(decode(load_item));                        \
         }                                                                                     \
     }
@@ -322,6 +370,8 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     DODT_FOR_SLOTS(DODT_PRO_LOAD)
     DODT_FOR_SLOTS(DODT_PRO_STORE)
     __syncthreads();
+    q0 = s_ctrl[0];
+    __syncthreads();                           // s_ctrl[0] is rewritten in the first step
     DODT_ADVANCE_LOAD()
     ok_regs = ok_issue;
     {
@@ -349,7 +399,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         const bool more = load_item < a.n_items;   // a real chunk is left to load
         const bool issue = !(a.debug & 2);         // production: always (a surplus load
                                                    // re-reads a valid address, no branch)
-        if (comp_ch == 0 && tid == 0)   // fetch the successor of the item being computed
+        if (comp_ch == 0 && tid == 0)   // fetch the item behind q0
             s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
 
         if (a.debug & 4) {
@@ -380,18 +430,26 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                 /* the next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc would */       \
                 /* otherwise sink them below to save registers and expose their latency) */   \
                 __builtin_amdgcn_sched_barrier(0);                                            \
-                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                 \
+                if constexpr (BF16) {                                                         \
                     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
                             acc[mt * NT + nt] =                                               \
-                                mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);      \
-                /* staging in the shadow of the MFMAs just issued */                          \
-                DODT_STAGE_TAP(TAP)                                                           \
-                _Pragma("unroll") for (int s = 2; s < 4; ++s)                                 \
-                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
-                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
-                            acc[mt * NT + nt] =                                               \
-                                mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);      \
+                                mfma_bf16(wf[cb][nt], xf[cb][mt], acc[mt * NT + nt]);         \
+                    DODT_STAGE_TAP(TAP)                                                       \
+                } else {                                                                      \
+                    _Pragma("unroll") for (int s = 0; s < 2; ++s)                             \
+                        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
+                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                 \
+                                acc[mt * NT + nt] =                                           \
+                                    mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);  \
+                    /* staging in the shadow of the MFMAs just issued */                      \
+                    DODT_STAGE_TAP(TAP)                                                       \
+                    _Pragma("unroll") for (int s = 2; s < 4; ++s)                             \
+                        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
+                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                 \
+                                acc[mt * NT + nt] =                                           \
+                                    mfma32(wf[cb][nt][s], xf[cb][mt][s], acc[mt * NT + nt]);  \
+                }                                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                            \
             }
 #define DODT_STAGE_ONE(J)                                                                     \
@@ -428,15 +486,22 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                             bW + w_base + (NEXT_TAP) * 2 * BN * 4 + nt * 128);                \
                 }                                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                            \
-                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                 \
+                if constexpr (BF16) {                                                         \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
                         acc[(CLS) * NT + nt] =                                                \
-                            mfma32(bw[cb][nt][s], af[AF][s], acc[(CLS) * NT + nt]);           \
-                DODT_STAGE_TAP(I)                                                             \
-                _Pragma("unroll") for (int s = 2; s < 4; ++s)                                 \
-                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
-                        acc[(CLS) * NT + nt] =                                                \
-                            mfma32(bw[cb][nt][s], af[AF][s], acc[(CLS) * NT + nt]);           \
+                            mfma_bf16(bw[cb][nt], af[AF], acc[(CLS) * NT + nt]);              \
+                    DODT_STAGE_TAP(I)                                                         \
+                } else {                                                                      \
+                    _Pragma("unroll") for (int s = 0; s < 2; ++s)                             \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
+                            acc[(CLS) * NT + nt] =                                            \
+                                mfma32(bw[cb][nt][s], af[AF][s], acc[(CLS) * NT + nt]);       \
+                    DODT_STAGE_TAP(I)                                                         \
+                    _Pragma("unroll") for (int s = 2; s < 4; ++s)                             \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
+                            acc[(CLS) * NT + nt] =                                            \
+                                mfma32(bw[cb][nt][s], af[AF][s], acc[(CLS) * NT + nt]);       \
+                }                                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                            \
             }
             //        step tap class input  next tap
@@ -452,7 +517,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         }
         if (more) {
             ok_regs = ok_issue;       // pre[] now holds (load_item, ld_ch)
-            DODT_ADVANCE_LOAD()       // uses next_item read after an earlier barrier
+            DODT_ADVANCE_LOAD()       // uses q0 / q1 read after earlier barriers
         }
         const bool item_done = (comp_ch + 1 == nchunks);
         if (item_done) {
@@ -473,14 +538,17 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                     const bool ok = st && y < a.H && x < a.W && y >= a.out_y0;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
+                        const int c0 = cur.ntile * BN + (wn * NT + nt) * 32;
+                        // bf16 kernels store bf16 CB16 maps, except the net's last layer (NHWC fp32)
                         if (pool)
-                            store_tile<true>(a, out, acc[mt * NT + nt],
-                                             cur.ntile * BN + (wn * NT + nt) * 32, lh,
-                                             y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                            store_tile<true, BF16, BF16>(a, out, acc[mt * NT + nt], c0, lh,
+                                                         y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                        else if (BF16 && !a.out_nhwc)
+                            store_tile<false, BF16, BF16>(a, out, acc[mt * NT + nt], c0, lh,
+                                                          y - a.out_y0, x, a.W, plane, ok, cur.frame);
                         else
-                            store_tile<false>(a, out, acc[mt * NT + nt],
-                                              cur.ntile * BN + (wn * NT + nt) * 32, lh,
-                                              y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                            store_tile<false, BF16, false>(a, out, acc[mt * NT + nt], c0, lh,
+                                                           y - a.out_y0, x, a.W, plane, ok, cur.frame);
                     }
                 }
                 if constexpr (kCanPool) {
@@ -492,7 +560,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                             const bool ok = st && y < a.H && x < a.W;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                pool_tile<TW>(a, acc[mt * NT + nt],
+                                pool_tile<TW, BF16, BF16>(a, acc[mt * NT + nt],
                                               acc[(Cfg::kRowsPerMT >= 2 ? mt : mt + 1) * NT + nt],
                                               cur.ntile * BN + (wn * NT + nt) * 32, lh, y, x,
                                               cur.frame, ok);
@@ -508,9 +576,10 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                 for (int cls = 0; cls < 4; ++cls)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        store_tile(a, out, acc[cls * NT + nt],
-                                   cur.ntile * BN + (wn * NT + nt) * 32, lh, 2 * y + (cls >> 1),
-                                   2 * x + (cls & 1), 2 * a.W, plane, ok);
+                        store_tile<false, BF16, BF16>(a, out, acc[cls * NT + nt],
+                                                      cur.ntile * BN + (wn * NT + nt) * 32, lh,
+                                                      2 * y + (cls >> 1), 2 * x + (cls & 1),
+                                                      2 * a.W, plane, ok);
             }
 #pragma unroll
             for (int k = 0; k < NACC; ++k)
@@ -519,10 +588,11 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         }
         __syncthreads();  // buffer buf^1 is complete, buffer buf is free, s_ctrl is visible
         buf ^= 1;
-        if (comp_ch == 0) next_item = s_ctrl[0];   // fetched at the top of this step
+        if (comp_ch == 0) q1 = s_ctrl[0];          // fetched at the top of this step
         if (item_done) {
             comp_ch = 0;
-            comp_item = next_item;
+            comp_item = q0;
+            q0 = q1;
         } else {
             ++comp_ch;
         }
@@ -563,7 +633,9 @@ struct SmallCfg {
     static_assert(CK % 2 == 0 && MTB % 4 == 0, "shape");
 };
 
-template <int TW, int MTB, int CK>
+// OUT16: the output is a CB16 bf16 map (the arithmetic stays fp32; the host permutes the
+// weights' output channels like for the bf16 kernels).
+template <int TW, int MTB, int CK, bool OUT16 = false>
 __global__ void __launch_bounds__(256)
 conv3x3_small_cin_kernel(const ConvArgs a) {
     using Cfg = SmallCfg<TW, MTB, CK>;
@@ -637,7 +709,8 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
         const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
         const int x = tx0 + li % TW;
-        store_tile(a, out, acc[mt], 0, lh, y, x, a.W, plane, y < a.H && x < a.W);
+        store_tile<false, OUT16, OUT16>(a, out, acc[mt], 0, lh, y, x, a.W, plane,
+                                        y < a.H && x < a.W);
     }
 }
 

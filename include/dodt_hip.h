@@ -174,6 +174,13 @@ typedef struct dodt_extractor dodt_extractor;
  * even out a layer's last round when it has the GPU to itself only add work when another
  * stream fills the idle CUs anyway. */
 #define DODT_EXTRACTOR_SHARED_GPU 0x100
+/* OR into `kind`: conv path on the bf16 MFMA (BASELINE.json configs[2]: "bf16 conv path").
+ * Inputs and weights of every conv are rounded to bf16 (nearest even), products accumulate
+ * in fp32, batch-norm + ReLU run in fp32, activations between layers are stored as bf16;
+ * the first layer's arithmetic, the network output and the bottleneck stay fp32.  The
+ * reference computes in fp32: with this flag conv outputs agree with an fp32
+ * run to ~1e-2 of their scale, not 1e-4 (tests/test_gpu_conv_bf16.py states the bars). */
+#define DODT_EXTRACTOR_BF16 0x200
 /* in_c: channels of the input tensor as stored (6 for BEV; 4 for the padded
  * image); pad_top: zero rows added on top (4 for BEV 700->704, 0 for images);
  * batch: frames processed per forward call (2 = both frames of a pair). */

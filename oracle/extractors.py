@@ -29,17 +29,23 @@ def pyramid_layer_names():
     return names
 
 
-def _cbr(x, p):
-    return tfops.bn_relu(tfops.conv2d_same(x, p['w']),
-                         p['beta'], p['mean'], p['var'])
+def _cbr(x, p, bf16=False, first=False, last=False):
+    """conv + BN + ReLU.  bf16: the device's bf16 conv path (include/dodt_hip.h
+    DODT_EXTRACTOR_BF16): weights rounded to bf16 (the input already is, except for the
+    first layer, whose arithmetic stays fp32), fp32 accumulation and BN/ReLU, output rounded
+    to bf16 unless it is the network output."""
+    w = p['w'] if (not bf16 or first) else tfops.round_bf16(p['w'])
+    y = tfops.bn_relu(tfops.conv2d_same(x, w), p['beta'], p['mean'], p['var'])
+    return tfops.round_bf16(y) if (bf16 and not last) else y
 
 
-def _ubr(x, p):
-    return tfops.bn_relu(tfops.conv2d_transpose_s2_same(x, p['w']),
-                         p['beta'], p['mean'], p['var'])
+def _ubr(x, p, bf16=False):
+    w = tfops.round_bf16(p['w']) if bf16 else p['w']
+    y = tfops.bn_relu(tfops.conv2d_transpose_s2_same(x, w), p['beta'], p['mean'], p['var'])
+    return tfops.round_bf16(y) if bf16 else y
 
 
-def encoder(x, params, collect=None):
+def encoder(x, params, collect=None, bf16=False):
     """Returns [conv1, conv2, conv3, conv4] block outputs (pre-pool)."""
     outs = []
     for bi, (block, reps) in enumerate(ENCODER):
@@ -47,26 +53,28 @@ def encoder(x, params, collect=None):
             x = tfops.max_pool_2x2(x)
         for r in range(reps):
             name = '%s_%d' % (block, r + 1)
-            x = _cbr(x, params[name])
+            x = _cbr(x, params[name], bf16, first=(name == 'conv1_1'))
             if collect is not None:
                 collect[name] = x
         outs.append(x)
     return outs
 
 
-def vgg_pyramid(x, params, pad_top=0, collect=None):
-    """x (H,W,C) float32 -> (H,W,32) full-resolution pyramid feature map."""
+def vgg_pyramid(x, params, pad_top=0, collect=None, conv_dtype='f32'):
+    """x (H,W,C) float32 -> (H,W,32) full-resolution pyramid feature map.
+    conv_dtype 'bf16' restates the device's bf16 conv path (see _cbr)."""
+    bf16 = conv_dtype == 'bf16'
     x = np.asarray(x, dtype=np.float32)
     if pad_top:
         x = np.concatenate(
             [np.zeros((pad_top,) + x.shape[1:], dtype=np.float32), x], axis=0)
-    c1, c2, c3, c4 = encoder(x, params, collect)
-    up3 = _ubr(c4, params['upconv3'])
-    f3 = _cbr(np.concatenate([c3, up3], axis=2), params['pyramid_fusion3'])
-    up2 = _ubr(f3, params['upconv2'])
-    f2 = _cbr(np.concatenate([c2, up2], axis=2), params['pyramid_fusion2'])
-    up1 = _ubr(f2, params['upconv1'])
-    f1 = _cbr(np.concatenate([c1, up1], axis=2), params['pyramid_fusion1'])
+    c1, c2, c3, c4 = encoder(x, params, collect, bf16)
+    up3 = _ubr(c4, params['upconv3'], bf16)
+    f3 = _cbr(np.concatenate([c3, up3], axis=2), params['pyramid_fusion3'], bf16)
+    up2 = _ubr(f3, params['upconv2'], bf16)
+    f2 = _cbr(np.concatenate([c2, up2], axis=2), params['pyramid_fusion2'], bf16)
+    up1 = _ubr(f2, params['upconv1'], bf16)
+    f1 = _cbr(np.concatenate([c1, up1], axis=2), params['pyramid_fusion1'], bf16, last=True)
     if collect is not None:
         collect.update(upconv3=up3, pyramid_fusion3=f3, upconv2=up2,
                        pyramid_fusion2=f2, upconv1=up1, pyramid_fusion1=f1)

@@ -27,6 +27,14 @@ F32 = np.float32
 BN_EPS = F32(0.001)
 
 
+def round_bf16(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: what the device's
+    v_cvt_pk_bf16_f32 stores between the layers of the bf16 conv path."""
+    u = np.ascontiguousarray(x, dtype=F32).view(np.uint32)
+    r = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return r.view(F32)
+
+
 def conv2d_same(x, w):
     """x (H,W,Cin), w (kh,kw,Cin,Cout) -> (H,W,Cout); stride 1, SAME.
     Accumulates tap by tap in float32 (one GEMM per tap)."""

@@ -1,0 +1,73 @@
+"""bf16 conv path (DODT_EXTRACTOR_BF16, BASELINE.json configs[2]) against its oracle.
+
+The oracle restates the device's scheme (oracle/extractors.py `_cbr`): weights and stored
+activations rounded to bf16 (nearest even), exact products, fp32 sums, fp32 BN + ReLU.  The
+two differ only where a pre-rounding fp32 sum lands within its summation-order noise (~1e-6
+relative) of a bf16 rounding boundary: a rare 1-ulp flip (2^-8 relative) that later layers
+average out.  Bars, stated per layer as fractions of the layer's activation scale:
+max error <= 1.6e-2 (two bf16 ulps at the top of the range), mean error <= 5e-4 (flips
+propagate: none in the first layers, a few per cent of the elements after ten).  Against the fp32 oracle (the reference's arithmetic) the bf16
+feature maps agree to 3e-2 of their scale -- the price of the bf16 path, not a parity claim.
+"""
+import numpy as np
+import pytest
+
+from dodt_amd import device, synth
+from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr, ImgVggPyr
+from oracle import extractors as oext
+from oracle import tfops
+
+pytestmark = pytest.mark.gpu
+
+
+def _bars(got, want, name, max_rel=1.6e-2, mean_rel=5e-4):
+    assert got.shape == want.shape, name
+    scale = float(np.abs(want).max()) + 1e-12
+    d = np.abs(got - want)
+    assert d.max() <= max_rel * scale, '%s: max err %g vs scale %g' % (name, d.max(), scale)
+    assert d.mean() <= mean_rel * scale, '%s: mean err %g vs scale %g' % (name, d.mean(), scale)
+
+
+def _run(cls, x, params, pad_top):
+    ex = cls(conv_dtype='bf16')
+    ex.load_params(params)
+    feat, ends = ex.build(x, with_bottleneck=True)
+    collect = [dict() for _ in range(x.shape[0])]
+    want = np.stack([oext.vgg_pyramid(x[f], params, pad_top=pad_top, collect=collect[f],
+                                      conv_dtype='bf16') for f in range(x.shape[0])])
+    for name in synth.PYRAMID_LAYERS[:-1]:
+        w = np.stack([c[name] for c in collect])
+        got = ex.activation(name)
+        assert np.array_equal(got, tfops.round_bf16(got)), name   # stored maps ARE bf16
+        _bars(got, w, name)
+    _bars(feat, want, 'feature_maps')
+    wb = np.stack([oext.bottleneck_1x1(want[f], params['bottleneck'])
+                   for f in range(x.shape[0])])
+    _bars(ends['bottleneck'], wb, 'bottleneck', max_rel=3e-2, mean_rel=2e-3)
+    # distance to the reference's fp32 arithmetic
+    f32 = np.stack([oext.vgg_pyramid(x[f], params, pad_top=pad_top) for f in range(x.shape[0])])
+    rel = np.abs(feat - f32).max() / (np.abs(f32).max() + 1e-12)
+    assert rel <= 3e-2, 'bf16 vs fp32 feature maps: %g' % rel
+    ex.close()
+    return rel
+
+
+@pytest.mark.parametrize('h,w', [(60, 96), (28, 40)])
+def test_bev_pyramid_bf16_all_layers(h, w):
+    rng = np.random.default_rng(h * w + 1)
+    x = rng.uniform(0, 1, size=(2, h, w, 6)).astype(np.float32)
+    x[x < 0.7] = 0
+    _run(BevVggPyr, x, synth.pyramid_params(6, seed=42), 4)
+
+
+def test_img_pyramid_bf16_all_layers():
+    rng = np.random.default_rng(78)
+    x = rng.normal(0, 60, size=(2, 48, 160, 3)).astype(np.float32)
+    _run(ImgVggPyr, x, synth.pyramid_params(3, seed=142), 0)
+
+
+def test_bf16_is_opt_in_and_checked():
+    with pytest.raises(ValueError):
+        BevVggPyr(conv_dtype='fp8')
+    ex = BevVggPyr()
+    assert ex._bf16 is False
