@@ -34,6 +34,9 @@ def parse():
     ap.add_argument('--heads', choices=('computed', 'injected'), default='computed',
                     help='dense heads + correlation branch on the device (the whole path), '
                          'or their outputs injected from HBM')
+    ap.add_argument('--conv-dtype', choices=('f32', 'bf16'), default='f32',
+                    help="arithmetic of the conv stacks: 'f32' = the reference's (fp32 MFMA), "
+                         "'bf16' = BASELINE configs[2]'s bf16 conv path (bf16 MFMA, fp32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -103,7 +106,8 @@ def main():
     computed = args.heads == 'computed'
     pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals,
                              pairs_per_step=pps,
-                             head_params=synth.head_params() if computed else None)
+                             head_params=synth.head_params() if computed else None,
+                             conv_dtype=args.conv_dtype)
 
     # detection records live in torch memory so that RCCL can ship them
     # (two of each: the pipeline alternates them by step parity)
@@ -191,7 +195,8 @@ def main():
         conv_ms += c.timer_stop() / reps
     flops = pipe.flops_per_step()
     achieved = flops / (conv_ms * 1e-3) / 1e12
-    peak = 157.3      # TFLOP/s, fp32 MFMA, MI355X_MICROARCH.md chip table
+    # TFLOP/s, dense MFMA peak of the conv dtype, MI355X_MICROARCH.md chip table
+    peak = 157.3 if args.conv_dtype == 'f32' else 2500.0
     # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
     # figure comes from the rocprofv3 --pmc passes over this same command (profiles/)
     traffic, traffic_src = None, None
@@ -217,7 +222,7 @@ def main():
             'unit': 'frame-pairs/s', 'n_gpus': n_gpus, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_dtype, 'data': 'synthetic',
             'config': {'workload': 'DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
                                    'pyramid_cars_with_aug_dt_5_tracking, %d proposals, '
                                    '%s' % (args.points // 1000, args.proposals,

@@ -44,7 +44,7 @@ class FramePairPipeline(object):
     def __init__(self, ctx, cfg, p2=synth.P2, r0_rect=synth.R0_RECT,
                  tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
                  n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None,
-                 pairs_per_step=1, side_streams=None, head_params=None):
+                 pairs_per_step=1, side_streams=None, head_params=None, conv_dtype='f32'):
         self.ctx = ctx
         self.cfg = cfg
         self.p2 = np.asarray(p2, dtype=np.float64)
@@ -88,10 +88,10 @@ class FramePairPipeline(object):
         self.d_cells = ctx.array(cells)
 
         # ---- extractors: every frame of the step is one batch ------------------------
-        self.bev_net = BevVggPyr(ctx=ctx, shared_gpu=True)
+        self.bev_net = BevVggPyr(ctx=ctx, shared_gpu=True, conv_dtype=conv_dtype)
         self.bev_net.load_params(bev_params or synth.pyramid_params(cfg['bev_depth'], 42))
         self.bev_net._ensure(self.nf, self.bev_h, self.bev_w, cfg['bev_depth'])
-        self.img_net = ImgVggPyr(ctx=self.img_ctx, shared_gpu=True)
+        self.img_net = ImgVggPyr(ctx=self.img_ctx, shared_gpu=True, conv_dtype=conv_dtype)
         self.img_net.load_params(img_params or synth.pyramid_params(cfg['img_depth'], 142))
         self.img_net._ensure(self.nf, self.img_h, self.img_w, 4)
         # conv inputs, double-buffered so that step k+1 is prepared under the convs of step k

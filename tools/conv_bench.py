@@ -11,10 +11,11 @@ from dodt_amd import config, device, synth  # noqa: E402
 from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr, ImgVggPyr  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dt = sys.argv[2] if len(sys.argv) > 2 else 'f32'
 ctx = device.default_context()
 cfg = config.PYRAMID_DODT
-bev = BevVggPyr(ctx=ctx); bev.load_params(synth.pyramid_params(6, 42)); bev._ensure(2, 700, 800, 6)
-img = ImgVggPyr(ctx=ctx); img.load_params(synth.pyramid_params(3, 142)); img._ensure(2, 360, 1200, 4)
+bev = BevVggPyr(ctx=ctx, conv_dtype=dt); bev.load_params(synth.pyramid_params(6, 42)); bev._ensure(2, 700, 800, 6)
+img = ImgVggPyr(ctx=ctx, conv_dtype=dt); img.load_params(synth.pyramid_params(3, 142)); img._ensure(2, 360, 1200, 4)
 rng = np.random.default_rng(0)
 p, s = bev.input_view()
 for f in range(2):
