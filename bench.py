@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--conv-dtype', choices=('f32', 'bf16'), default='f32',
                     help="arithmetic of the conv stacks: 'f32' = the reference's (fp32 MFMA), "
                          "'bf16' = BASELINE configs[2]'s bf16 conv path (bf16 MFMA, fp32 accumulate)")
+    ap.add_argument('--no-alt', action='store_true',
+                    help='skip the short extra run with the other conv arithmetic')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -104,96 +106,125 @@ def main():
     ctx = device.Context(local_rank, stream=stream)
     pps = args.pairs_per_step
     computed = args.heads == 'computed'
-    pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals,
-                             pairs_per_step=pps,
-                             head_params=synth.head_params() if computed else None,
-                             conv_dtype=args.conv_dtype)
+    made = []   # pipelines built so far: later ones reuse the first one's streams
 
-    # detection records live in torch memory so that RCCL can ship them
-    # (two of each: the pipeline alternates them by step parity)
-    rec = [torch.zeros((pps, 2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
-           for _ in range(2)]
-    cnt = [torch.zeros((pps, 2), dtype=torch.int32, device='cuda') for _ in range(2)]
-    pipe.use_record_buffers([t.data_ptr() for t in rec], [t.data_ptr() for t in cnt])
-    gathered = torch.zeros((world * pps, 2, MAX_DET, REC_COLS), dtype=torch.float32,
-                           device='cuda')
-    gathered_cnt = torch.zeros((world * pps, 2), dtype=torch.int32, device='cuda')
+    def measure(conv_dtype, steps, warmup):
+        """`steps` timed steps of the pipeline built for conv_dtype, then the conv stacks
+        alone (roofline).  Returns a dict of raw measurements."""
+        pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals,
+                                 pairs_per_step=pps,
+                                 head_params=synth.head_params() if computed else None,
+                                 conv_dtype=conv_dtype,
+                                 reuse_streams_of=made[0] if made else None)
+        made.append(pipe)
 
-    # a small ring of distinct synthetic batches, resident in HBM before timing starts;
-    # every pair of a batch comes from a different sequence (they are independent)
-    n_batches = 2
-    batches = []
-    for i in range(n_batches):
-        pts, imgs, heads = [], [], []
-        for j in range(pps):
-            seq = (rank * n_batches + i) * pps + j
-            for f in (2 * i, 2 * i + 2):                             # tau = 2
-                pts.append(synth.lidar_frame(seq, f, args.points))
-                imgs.append(ctx.array(synth.image_frame(seq, f)))
-                if not computed:
-                    heads.append({k: ctx.array(v) for k, v in
-                                  synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()})
-        batches.append(dict(pts=[ctx.array(p) for p in pts], n=[len(p) for p in pts],
-                            imgs=imgs, heads=None if computed else heads))
+        # detection records live in torch memory so that RCCL can ship them
+        # (two of each: the pipeline alternates them by step parity)
+        rec = [torch.zeros((pps, 2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
+               for _ in range(2)]
+        cnt = [torch.zeros((pps, 2), dtype=torch.int32, device='cuda') for _ in range(2)]
+        pipe.use_record_buffers([t.data_ptr() for t in rec], [t.data_ptr() for t in cnt])
+        gathered = torch.zeros((world * pps, 2, MAX_DET, REC_COLS), dtype=torch.float32,
+                               device='cuda')
+        gathered_cnt = torch.zeros((world * pps, 2), dtype=torch.int32, device='cuda')
 
-    state = {'n': 0, 'par': 0}
+        # a small ring of distinct synthetic batches, resident in HBM before timing starts;
+        # every pair of a batch comes from a different sequence (they are independent)
+        n_batches = 2
+        batches = []
+        for i in range(n_batches):
+            pts, imgs, heads = [], [], []
+            for j in range(pps):
+                seq = (rank * n_batches + i) * pps + j
+                for f in (2 * i, 2 * i + 2):                             # tau = 2
+                    pts.append(synth.lidar_frame(seq, f, args.points))
+                    imgs.append(ctx.array(synth.image_frame(seq, f)))
+                    if not computed:
+                        heads.append({k: ctx.array(v) for k, v in
+                                      synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()})
+            batches.append(dict(pts=[ctx.array(p) for p in pts], n=[len(p) for p in pts],
+                                imgs=imgs, heads=None if computed else heads))
 
-    def gather(par):
+        state = {'n': 0, 'par': 0}
+
+        def gather(par):
+            if world > 1:
+                sharding.all_gather_records(dist, rec[par], cnt[par], gathered, gathered_cnt)
+
+        def step(i):
+            p = batches[i % n_batches]
+            par = pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
+            if state['n'] > 0:     # records of the previous step are complete on this stream
+                gather(1 - par)
+            state['n'] += 1
+            state['par'] = par
+
+        def drain():
+            pipe.finish()
+            if state['n'] > 0:
+                gather(state['par'])
+            state['n'] = 0
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # steps are pipelined two deep inside pipe.run(); finish() drains the last one, so
+        # exactly `steps` complete steps (convs AND tails) lie inside the timed region
+        for i in range(warmup):
+            step(i)
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3   # host side of a step
+        drain()
+        barrier()
+        elapsed = time.perf_counter() - t0
         if world > 1:
-            sharding.all_gather_records(dist, rec[par], cnt[par], gathered, gathered_cnt)
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
 
-    def step(i):
-        p = batches[i % n_batches]
-        par = pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
-        if state['n'] > 0:     # records of the previous step are complete on this stream
-            gather(1 - par)
-        state['n'] += 1
-        state['par'] = par
+        # ---- roofline of the dominant kernel family: the conv stacks -----------------------
+        # measured live with HIP events on the stream the kernels run on
+        # (each net alone on its own stream, so the kernel durations do not overlap)
+        reps = max(3, min(steps, 10))
+        barrier()
+        conv_ms = 0.0
+        for net, c, f, b in ((pipe.bev_net, ctx, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck']),
+                             (pipe.img_net, pipe.img_ctx, pipe.feat[0]['img_feat'],
+                              pipe.feat[0]['img_bneck'])):
+            c.sync()
+            c.timer_start()
+            for _ in range(reps):
+                net.forward_device(None, f, b)
+            conv_ms += c.timer_stop() / reps
+        res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
+                   flops=pipe.flops_per_step(), head_gflop=pipe.head_flops_per_step() / 1e9,
+                   anchors=list(pipe.last_anchor_counts), steps=steps)
+        pipe.close()
+        return res
 
-    def drain():
-        pipe.finish()
-        if state['n'] > 0:
-            gather(state['par'])
-        state['n'] = 0
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # steps are pipelined two deep inside pipe.run(); finish() drains the last one, so
-    # exactly `steps` complete steps (convs AND tails) lie inside the timed region
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host side of a step
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- roofline of the dominant kernel family: the conv stacks -----------------------
-    # measured live with HIP events on the stream the kernels run on
-    # (each net alone on its own stream, so the kernel durations do not overlap)
-    reps = max(3, min(args.steps, 10))
-    barrier()
-    conv_ms = 0.0
-    for net, c, f, b in ((pipe.bev_net, ctx, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck']),
-                         (pipe.img_net, pipe.img_ctx, pipe.feat[0]['img_feat'],
-                          pipe.feat[0]['img_bneck'])):
-        c.sync()
-        c.timer_start()
-        for _ in range(reps):
-            net.forward_device(None, f, b)
-        conv_ms += c.timer_stop() / reps
-    flops = pipe.flops_per_step()
+    m = measure(args.conv_dtype, args.steps, args.warmup)
+    elapsed, host_enqueue_ms, conv_ms, reps = m['elapsed'], m['host_enqueue_ms'], m['conv_ms'], m['reps']
+    alt = None
+    if not args.no_alt:
+        # the other conv arithmetic, same workload, a shorter run: reported beside the main
+        # measurement, never part of `value`
+        other = 'bf16' if args.conv_dtype == 'f32' else 'f32'
+        k = max(5, args.steps // 2)
+        a = measure(other, k, 2)
+        alt = {'dtype': other, 'value': round(world * k * pps / a['elapsed'], 3),
+               'unit': 'frame-pairs/s', 'steps': k, 'ms_per_step': round(a['elapsed'] / k * 1e3, 4),
+               'conv_stacks_tflops': round(a['flops'] / (a['conv_ms'] * 1e-3) / 1e12, 2),
+               'conv_stacks_ms': round(a['conv_ms'], 4),
+               'note': "bf16 = BASELINE.json configs[2]'s bf16 conv path (bf16 MFMA, fp32 "
+                       'accumulate; parity bars in tests/test_gpu_conv_bf16.py); f32 = the '
+                       "reference's arithmetic"}
+    flops = m['flops']
     achieved = flops / (conv_ms * 1e-3) / 1e12
     # TFLOP/s, dense MFMA peak of the conv dtype, MI355X_MICROARCH.md chip table
     peak = 157.3 if args.conv_dtype == 'f32' else 2500.0
@@ -228,11 +259,13 @@ def main():
                                    '%s' % (args.points // 1000, args.proposals,
                                            'S+T path: correlation + dense heads on the device'
                                            if computed else 'S path (heads injected)'),
-                       'head_gflop_per_step': round(pipe.head_flops_per_step() / 1e9, 2),
+                       'head_gflop_per_step': round(m['head_gflop'], 2),
                        'pairs_per_step_per_gpu': pps, 'parallelism': 'pair-shard x%d' % world,
-                       'anchors_kept': pipe.last_anchor_counts},
+                       'anchors_kept': m['anchors']},
             'roofline': roofline,
         }
+        if alt is not None:
+            out['alt'] = alt
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(cfg, synth, args.cpu_seconds, computed)
         print(json.dumps(out))

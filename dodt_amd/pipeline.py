@@ -44,7 +44,8 @@ class FramePairPipeline(object):
     def __init__(self, ctx, cfg, p2=synth.P2, r0_rect=synth.R0_RECT,
                  tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
                  n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None,
-                 pairs_per_step=1, side_streams=None, head_params=None, conv_dtype='f32'):
+                 pairs_per_step=1, side_streams=None, head_params=None, conv_dtype='f32',
+                 reuse_streams_of=None):
         self.ctx = ctx
         self.cfg = cfg
         self.p2 = np.asarray(p2, dtype=np.float64)
@@ -58,25 +59,15 @@ class FramePairPipeline(object):
         self.bev_extents_flat = np.asarray(cfg['bev_extents'], np.float64).reshape(-1)
         self.bp = ops.make_bev_params(cfg, synth.velo_to_cam(r0_rect, tr_velo_to_cam),
                                       self.p2, self.image_wh)
-        # streams: conv stacks of the two nets side by side, per-frame work on its own
-        self.img_ctx = device.Context(ctx.device_id)
-        n_side = min(self.nf, 2) if side_streams is None else int(side_streams)
-        hp = os.environ.get('DODT_PIPE_PRIO', '0') == '1'
-        self.sides = [device.Context(ctx.device_id, high_priority=hp)
-                      for _ in range(max(n_side, 1))]   # tails
-        # ROCm maps a process's streams onto 4 hardware queues; a fifth stream shares a queue
-        # with another one and runs behind its launches (measured: 6 streams 164, 5 streams
-        # 180, 4 streams 191 pairs/s), so by default a frame's prep and tail share a stream
-        mode = os.environ.get('DODT_PIPE_STREAMS', 'shared')
-        if mode == 'shared':      # frame f's prep and tail on one stream
-            self.preps = self.sides
-        elif mode == 'one':       # all preps on one extra stream
-            one = device.Context(ctx.device_id, high_priority=hp)
-            self.preps = [one for _ in self.sides]
+        # streams: conv stacks of the two nets side by side, per-frame work on its own.
+        # A second pipeline in the same process takes the first one's streams
+        # (`reuse_streams_of`): new ones would share hardware queues with them (see below).
+        if reuse_streams_of is not None:
+            self.img_ctx = reuse_streams_of.img_ctx
+            self.sides = reuse_streams_of.sides
+            self.preps = reuse_streams_of.preps
         else:
-            self.preps = [device.Context(ctx.device_id, high_priority=hp)
-                          for _ in range(max(n_side, 1))]
-
+            self._make_streams(ctx, side_streams)
         # ---- constants of the configuration, resident on the device ----------------
         boxes = gen.tile_anchors_3d(cfg['area_extents'], cfg['anchor_sizes'],
                                     cfg['anchor_stride'], cfg['ground_plane'])
@@ -164,6 +155,25 @@ class FramePairPipeline(object):
             if slot < 16:
                 c.mark(slot)
                 self.marks['%d:%s' % (step, name)] = (c, slot)
+
+    def _make_streams(self, ctx, side_streams):
+        self.img_ctx = device.Context(ctx.device_id)
+        n_side = min(self.nf, 2) if side_streams is None else int(side_streams)
+        hp = os.environ.get('DODT_PIPE_PRIO', '0') == '1'
+        self.sides = [device.Context(ctx.device_id, high_priority=hp)
+                      for _ in range(max(n_side, 1))]   # tails
+        # ROCm maps a process's streams onto 4 hardware queues; a fifth stream shares a queue
+        # with another one and runs behind its launches (measured: 6 streams 164, 5 streams
+        # 180, 4 streams 191 pairs/s), so by default a frame's prep and tail share a stream
+        mode = os.environ.get('DODT_PIPE_STREAMS', 'shared')
+        if mode == 'shared':      # frame f's prep and tail on one stream
+            self.preps = self.sides
+        elif mode == 'one':       # all preps on one extra stream
+            one = device.Context(ctx.device_id, high_priority=hp)
+            self.preps = [one for _ in self.sides]
+        else:
+            self.preps = [device.Context(ctx.device_id, high_priority=hp)
+                          for _ in range(max(n_side, 1))]
 
     def _views(self, arr, shape):
         n = int(np.prod(shape)) * 4

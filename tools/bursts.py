@@ -8,7 +8,7 @@ for r in rows:
     r['s'] = int(r['Start_Timestamp'])
     r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
-marks = [r['s'] for r in rows if 'small_cin' in r['Kernel_Name'] and '6>' in r['Kernel_Name']]
+marks = [r['s'] for r in rows if 'small_cin' in r['Kernel_Name'] and (', 6>' in r['Kernel_Name'] or ', 6, ' in r['Kernel_Name'])]
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 t0 = marks[first]
 print('bev conv starts (ms):', [round((m - t0) / 1e6, 2) for m in marks[first:first + 6]])

@@ -10,9 +10,11 @@ from dodt_amd import config, device, synth  # noqa: E402
 from dodt_amd.pipeline import FramePairPipeline  # noqa: E402
 
 computed = '--injected' not in sys.argv
+conv_dtype = 'bf16' if '--bf16' in sys.argv else 'f32'
 ctx = device.default_context()
 pipe = FramePairPipeline(ctx, config.PYRAMID_DODT,
-                         head_params=synth.head_params() if computed else None)
+                         head_params=synth.head_params() if computed else None,
+                         conv_dtype=conv_dtype)
 frames = (0, 2)
 pts = [ctx.array(synth.lidar_frame(0, f)) for f in frames]
 imgs = [ctx.array(synth.image_frame(0, f)) for f in frames]

@@ -11,7 +11,7 @@ for r in rows:
     r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
 # steady state: from the 3rd-last to the last first-layer BEV kernel
-marks = [r['s'] for r in rows if 'small_cin' in r['Kernel_Name'] and '6>' in r['Kernel_Name']]
+marks = [r['s'] for r in rows if 'small_cin' in r['Kernel_Name'] and (', 6>' in r['Kernel_Name'] or ', 6, ' in r['Kernel_Name'])]
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0     # marks to drop at the end (roofline reps)
 t0, t1 = marks[-n_steps - 1 - skip], marks[-1 - skip]

@@ -13,8 +13,8 @@ BEV = [('conv1_1', 1.95), ('conv1_2', 10.38), ('pool', 0), ('conv2_1', 5.19), ('
        ('fusion1', 20.76), ('bneck', 0)]
 IMG = [(n, g * (0.75 / 1.95 if n == 'conv1_1' else 432000.0 / 563200.0)) for n, g in BEV]
 names = [r['Kernel_Name'] for r in rows]
-bev_idx = [i for i, n in enumerate(names) if 'small_cin' in n and '6>' in n]
-img_idx = [i for i, n in enumerate(names) if 'small_cin' in n and '4>' in n]
+bev_idx = [i for i, n in enumerate(names) if re.search(r'small_cin_kernel<\d+, \d+, 6[,>]', n)]
+img_idx = [i for i, n in enumerate(names) if re.search(r'small_cin_kernel<\d+, \d+, 4[,>]', n)]
 def dur(r):
     return (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 
