@@ -345,11 +345,15 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         dbg_r0 = __builtin_amdgcn_s_memrealtime();
     }
     int load_item = comp_item, load_ch = 0;    // chunk whose loads are issued next
-    // the two items after comp_item (from the counter): q0 is fetched before the prologue's
-    // barrier, after that the item behind q0 is fetched during every item's first step.  The
-    // load pointer runs two chunks ahead, i.e. at most one item ahead (host: nchunks >= 2).
+    // Items after comp_item come from the counter, one fetch during every item's first step.
+    // With >= 4 chunks per item that fetch is the item's successor q0 (needed by the loads two
+    // chunks before the item ends).  Items of 2-3 chunks (bf16 layers with 32 input channels;
+    // fp32 layers always have >= 4) need their successor from the start: then q0 is fetched
+    // before the prologue's barrier and each later fetch is the item behind it, q1 ("deep").
+    // Claiming no further ahead than necessary keeps the last round even.
+    const bool deep = BF16 && nchunks < 4;
     int q0 = a.n_items, q1 = a.n_items;
-    if (tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+    if (deep && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
     setup_loads(decode(load_item));
     unsigned ok_regs = ok_issue;               // mask of the data sitting in pre[]
     // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
@@ -370,8 +374,10 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     DODT_FOR_SLOTS(DODT_PRO_LOAD)
     DODT_FOR_SLOTS(DODT_PRO_STORE)
     __syncthreads();
-    q0 = s_ctrl[0];
-    __syncthreads();                           // s_ctrl[0] is rewritten in the first step
+    if (deep) {
+        q0 = s_ctrl[0];
+        __syncthreads();                       // s_ctrl[0] is rewritten in the first step
+    }
     DODT_ADVANCE_LOAD()
     ok_regs = ok_issue;
     {
@@ -399,7 +405,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         const bool more = load_item < a.n_items;   // a real chunk is left to load
         const bool issue = !(a.debug & 2);         // production: always (a surplus load
                                                    // re-reads a valid address, no branch)
-        if (comp_ch == 0 && tid == 0)   // fetch the item behind q0
+        if (comp_ch == 0 && tid == 0)   // fetch the successor (deep: the item behind q0)
             s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
 
         if (a.debug & 4) {
@@ -588,11 +594,14 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         }
         __syncthreads();  // buffer buf^1 is complete, buffer buf is free, s_ctrl is visible
         buf ^= 1;
-        if (comp_ch == 0) q1 = s_ctrl[0];          // fetched at the top of this step
+        if (comp_ch == 0) {                        // fetched at the top of this step
+            if (deep) q1 = s_ctrl[0];
+            else q0 = s_ctrl[0];
+        }
         if (item_done) {
             comp_ch = 0;
             comp_item = q0;
-            q0 = q1;
+            if (deep) q0 = q1;
         } else {
             ++comp_ch;
         }
