@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--conv-dtype', choices=('f32', 'bf16'), default='f32',
                     help="arithmetic of the conv stacks: 'f32' = the reference's (fp32 MFMA), "
                          "'bf16' = BASELINE configs[2]'s bf16 conv path (bf16 MFMA, fp32 accumulate)")
+    ap.add_argument('--head-dtype', choices=('f32', 'bf16'), default='f32',
+                    help='arithmetic of the dense heads (fp32 MFMA or bf16 MFMA, fp32 accumulate)')
     ap.add_argument('--no-alt', action='store_true',
                     help='skip the short extra run with the other conv arithmetic')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -108,13 +110,13 @@ def main():
     computed = args.heads == 'computed'
     made = []   # pipelines built so far: later ones reuse the first one's streams
 
-    def measure(conv_dtype, steps, warmup):
+    def measure(conv_dtype, steps, warmup, head_dtype='f32'):
         """`steps` timed steps of the pipeline built for conv_dtype, then the conv stacks
         alone (roofline).  Returns a dict of raw measurements."""
         pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals,
                                  pairs_per_step=pps,
                                  head_params=synth.head_params() if computed else None,
-                                 conv_dtype=conv_dtype,
+                                 conv_dtype=conv_dtype, head_dtype=head_dtype,
                                  reuse_streams_of=made[0] if made else None)
         made.append(pipe)
 
@@ -208,22 +210,26 @@ def main():
         pipe.close()
         return res
 
-    m = measure(args.conv_dtype, args.steps, args.warmup)
+    m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype)
     elapsed, host_enqueue_ms, conv_ms, reps = m['elapsed'], m['host_enqueue_ms'], m['conv_ms'], m['reps']
     alt = None
     if not args.no_alt:
         # the other conv arithmetic, same workload, a shorter run: reported beside the main
         # measurement, never part of `value`
-        other = 'bf16' if args.conv_dtype == 'f32' else 'f32'
         k = max(5, args.steps // 2)
-        a = measure(other, k, 2)
-        alt = {'dtype': other, 'value': round(world * k * pps / a['elapsed'], 3),
-               'unit': 'frame-pairs/s', 'steps': k, 'ms_per_step': round(a['elapsed'] / k * 1e3, 4),
-               'conv_stacks_tflops': round(a['flops'] / (a['conv_ms'] * 1e-3) / 1e12, 2),
-               'conv_stacks_ms': round(a['conv_ms'], 4),
-               'note': "bf16 = BASELINE.json configs[2]'s bf16 conv path (bf16 MFMA, fp32 "
-                       'accumulate; parity bars in tests/test_gpu_conv_bf16.py); f32 = the '
-                       "reference's arithmetic"}
+
+        def short(conv_dtype, head_dtype):
+            a = measure(conv_dtype, k, 2, head_dtype)
+            return {'conv_dtype': conv_dtype, 'head_dtype': head_dtype,
+                    'value': round(world * k * pps / a['elapsed'], 3), 'unit': 'frame-pairs/s',
+                    'steps': k, 'ms_per_step': round(a['elapsed'] / k * 1e3, 4),
+                    'conv_stacks_tflops': round(a['flops'] / (a['conv_ms'] * 1e-3) / 1e12, 2),
+                    'conv_stacks_ms': round(a['conv_ms'], 4)}
+        other = 'bf16' if args.conv_dtype == 'f32' else 'f32'
+        alt = {'note': "bf16 conv = BASELINE.json configs[2]'s bf16 conv path (bf16 MFMA, fp32 "
+                       'accumulate, bf16 maps between layers; bars in tests/test_gpu_conv_bf16.py); '
+                       "bf16 heads = the same for the FC layers; f32 = the reference's arithmetic",
+               'runs': [short(other, 'f32')] + ([short('bf16', 'bf16')] if computed else [])}
     flops = m['flops']
     achieved = flops / (conv_ms * 1e-3) / 1e12
     # TFLOP/s, dense MFMA peak of the conv dtype, MI355X_MICROARCH.md chip table
@@ -254,6 +260,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_dtype, 'data': 'synthetic',
+            'head_dtype': args.head_dtype,
             'config': {'workload': 'DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
                                    'pyramid_cars_with_aug_dt_5_tracking, %d proposals, '
                                    '%s' % (args.points // 1000, args.proposals,

@@ -16,6 +16,8 @@ PTS_VELO_XYZI, PTS_CAM_3XN = 0, 1
 EXTRACTOR_VGG_PYR = 0
 EXTRACTOR_SHARED_GPU = 0x100
 EXTRACTOR_BF16 = 0x200
+FC_RELU = 1
+FC_BF16 = 2
 
 
 class DodtError(RuntimeError):
@@ -94,6 +96,7 @@ SIGNATURES = {
                                   _pf]),
     'dodt_correlation': (_i, [_vp, _pf, _pf, _i, _i, _i, _i, _i, _i, _pf]),
     'dodt_fc_create': (_i, [_vp, _i, _i, _hf, _hf, _i, C.POINTER(_vp)]),
+    'dodt_fc_create_ex': (_i, [_vp, _i, _i, _hf, _hf, _i, C.POINTER(_vp)]),
     'dodt_fc_destroy': (_i, [_vp]),
     'dodt_fc_forward': (_i, [_vp, _vp, _pf, _pf, _i, _i, _pi32, _pf, _i]),
     'dodt_fc_flops': (_d, [_vp, _i]),

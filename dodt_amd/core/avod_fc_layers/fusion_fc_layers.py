@@ -12,11 +12,11 @@ class EarlyFusionFcLayers(object):
     `outputs` names the output layers in params, e.g. ('cls_out', 'off_out') for box_4c
     (no angle vectors: avod_fc_layer_utils.py:11-17) or ('off_out',) for the corr head."""
 
-    def __init__(self, ctx, params, outputs=('cls_out', 'off_out')):
+    def __init__(self, ctx, params, outputs=('cls_out', 'off_out'), dtype='f32'):
         names = sorted(k for k in params if k.startswith('fc'))
-        self.hidden = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], True)
+        self.hidden = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], True, dtype=dtype)
                        for k in names]
-        self.outputs = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], False)
+        self.outputs = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], False, dtype=dtype)
                         for k in outputs]
         self.width = max(l.N for l in self.hidden)
         self.ctx = ctx

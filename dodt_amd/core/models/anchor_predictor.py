@@ -7,7 +7,7 @@ from dodt_amd import ops
 
 
 class AnchorPredictor(object):
-    def __init__(self, ctx, params):
+    def __init__(self, ctx, params, dtype='f32'):
         """params[name] = dict(w, b), names cls_fc6/7/8 and reg_fc6/7/8, TF conv shapes."""
         def mat(name):
             w = np.asarray(params[name]['w'], np.float32)
@@ -19,11 +19,11 @@ class AnchorPredictor(object):
             raise ValueError('cls_fc6 and reg_fc6 must have the same size')
         # both branches read the same fused crop: one launch, columns [cls | reg]
         self.fc6 = ops.FullyConnected(ctx, np.concatenate([wc, wr], 1),
-                                      np.concatenate([bc, br]), True)
-        self.cls7 = ops.FullyConnected(ctx, *mat('cls_fc7'), relu=True)
-        self.reg7 = ops.FullyConnected(ctx, *mat('reg_fc7'), relu=True)
-        self.cls8 = ops.FullyConnected(ctx, *mat('cls_fc8'), relu=False)
-        self.reg8 = ops.FullyConnected(ctx, *mat('reg_fc8'), relu=False)
+                                      np.concatenate([bc, br]), True, dtype=dtype)
+        self.cls7 = ops.FullyConnected(ctx, *mat('cls_fc7'), relu=True, dtype=dtype)
+        self.reg7 = ops.FullyConnected(ctx, *mat('reg_fc7'), relu=True, dtype=dtype)
+        self.cls8 = ops.FullyConnected(ctx, *mat('cls_fc8'), relu=False, dtype=dtype)
+        self.reg8 = ops.FullyConnected(ctx, *mat('reg_fc8'), relu=False, dtype=dtype)
         self.layers = [self.fc6, self.cls7, self.reg7, self.cls8, self.reg8]
         self.ctx = ctx
 

@@ -44,15 +44,28 @@ struct GemmArgs {
     const int* d_m;    // may be NULL: rows >= *d_m are skipped
 };
 
-template <int BM, int BN, int WM, int WN, bool XVEC, int WBN, int kBK, bool FUSE>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float pack_bf16(float lo, float hi) {   // round to nearest even
+    return __builtin_bit_cast(float, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+// kBK = k per stage.  BF16: x is rounded to bf16 on its way into LDS, the weights are stored
+// as bf16, one v_mfma_f32_32x32x16_bf16 replaces four fp32 MFMAs; a 16-byte LDS fragment
+// holds KB = 8 k-values instead of 4, so the LDS images of a stage have the geometry of an
+// fp32 stage of half the depth (G).
+template <int BM, int BN, int WM, int WN, bool XVEC, int WBN, int kBK, bool FUSE, bool BF16>
 __global__ void __launch_bounds__(256)
 fc_mfma_kernel(const GemmArgs a) {
     constexpr int MT = BM / 32 / WM, NT = BN / 32 / WN;
-    constexpr int kXS = kBK + 4;             // LDS floats per x row
-    constexpr int XITEMS = BM * (kBK / 4);   // float4 per stage
-    constexpr int WITEMS = kBK * BN / 4;
+    constexpr int KB = BF16 ? 8 : 4;         // k per 16-byte fragment
+    constexpr int G = kBK * 4 / KB;          // floats of LDS per x row and stage
+    constexpr int kXS = G + 4;               // LDS floats per x row
+    constexpr int XITEMS = BM * (G / 4);     // 16-byte fragments per stage
+    constexpr int WITEMS = G * BN / 4;
     constexpr int NX = (XITEMS + 255) / 256, NW = (WITEMS + 255) / 256;
-    constexpr int kBuf = BM * kXS + kBK * BN;  // floats per LDS buffer
+    constexpr int kBuf = BM * kXS + G * BN;  // floats per LDS buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,11 +78,13 @@ fc_mfma_kernel(const GemmArgs a) {
     // weights are blocked WBN columns wide; this kernel's BN columns are a slice of them
     static_assert(WBN % BN == 0, "tile must divide the blocked width");
     const f32x4* wblk = reinterpret_cast<const f32x4*>(a.w) +
-                        (size_t)(nt0 * BN / WBN) * (a.Kp / 8) * 2 * WBN + (nt0 * BN) % WBN;
+                        (size_t)(nt0 * BN / WBN) * (a.Kp / (2 * KB)) * 2 * WBN + (nt0 * BN) % WBN;
 
     // staging slot j < NX: x float4 (tid + 256 j); slot NX + j: weight float4 (tid + 256 j).
     // Loads are unconditional (clamped addresses), zero-fill happens by select.
-    f32x4 pre[NX + NW];
+    constexpr int XV = KB / 4;     // float4 loads per x fragment
+    f32x4 prex[NX][XV];            // x slots: raw floats of one fragment
+    f32x4 pre[NX + NW];            // weight slots (x slots of this array are unused)
     constexpr int NSLOT = NX + NW;
     // per-slot addressing, hoisted out of the k loop (the loop body must leave the issue
     // slots between MFMAs to the loads and LDS writes, not to integer arithmetic)
@@ -80,10 +95,10 @@ fc_mfma_kernel(const GemmArgs a) {
     for (int j = 0; j < NSLOT; ++j) {
         if (j < NX) {
             const int t = tid + j * 256;
-            const int row = min(t / (kBK / 4), BM - 1), q = t % (kBK / 4);
+            const int row = min(t / (G / 4), BM - 1), q = t % (G / 4);
             const int m = min(m0 + row, M - 1);          // clamp: surplus rows are never stored
-            g_off[j] = m * a.ldx + q * 4;
-            k_q[j < NX ? j : 0] = q * 4;
+            g_off[j] = m * a.ldx + q * KB;
+            k_q[j < NX ? j : 0] = q * KB;
             l_off[j] = row * kXS + q * 4;
         } else {
             const int t = min(tid + (j - NX) * 256, WITEMS - 1);
@@ -93,38 +108,53 @@ fc_mfma_kernel(const GemmArgs a) {
     }
     // loads only ISSUE here; averaging (FUSE) and the zero fill of the K padding happen when
     // the registers are written to LDS a stage later, so no load is waited for on the spot
-    f32x4 pre2[FUSE ? NX : 1];
+    f32x4 pre2[FUSE ? NX : 1][XV];
     auto load_slot = [&](int j, int st) {
         if (j < NX) {
-            const int kk = st * kBK + k_q[j < NX ? j : 0];
+            const int jx = j < NX ? j : 0;
+            const int kk = st * kBK + k_q[jx];
             if constexpr (XVEC) {
-                const int back = max(kk + 4 - a.K, 0);   // > 0 only in the padded last stage
-                pre[j] = *reinterpret_cast<const f32x4*>(a.x + g_off[j] + st * kBK - back);
-                if constexpr (FUSE)
-                    pre2[j < NX ? j : 0] =
-                        *reinterpret_cast<const f32x4*>(a.x2 + g_off[j] + st * kBK - back);
+                const int back = max(kk + KB - a.K, 0);   // > 0 only in the padded last stage
+#pragma unroll
+                for (int i = 0; i < XV; ++i) {
+                    prex[jx][i] = *reinterpret_cast<const f32x4*>(a.x + g_off[j] + st * kBK +
+                                                                  4 * i - back);
+                    if constexpr (FUSE)
+                        pre2[jx][i] = *reinterpret_cast<const f32x4*>(a.x2 + g_off[j] + st * kBK +
+                                                                      4 * i - back);
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < KB; ++e) {
                     const int back = max(kk + e + 1 - a.K, 0);
-                    pre[j][e] = a.x[g_off[j] + st * kBK + e - back];
+                    prex[jx][e / 4][e % 4] = a.x[g_off[j] + st * kBK + e - back];
                     if constexpr (FUSE)
-                        pre2[j < NX ? j : 0][e] = a.x2[g_off[j] + st * kBK + e - back];
+                        pre2[jx][e / 4][e % 4] = a.x2[g_off[j] + st * kBK + e - back];
                 }
             }
         } else {
-            pre[j] = wblk[(size_t)st * (kBK / 4 * WBN) + g_off[j]];
+            pre[j] = wblk[(size_t)st * (G / 4 * WBN) + g_off[j]];
         }
     };
     auto store_slot = [&](int j, int buf, int st) {   // st: the stage the registers hold
         if (j < NX) {
-            f32x4 v = pre[j];
-            if constexpr (FUSE) v = (v + pre2[j < NX ? j : 0]) / 2.0f;
-            const int kk = st * kBK + k_q[j < NX ? j : 0];
+            const int jx = j < NX ? j : 0;
+            const int kk = st * kBK + k_q[jx];
+            float v[KB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (kk + e < a.K) ? v[e] : 0.0f;
+            for (int e = 0; e < KB; ++e) {
+                float t = prex[jx][e / 4][e % 4];
+                if constexpr (FUSE) t = (t + pre2[jx][e / 4][e % 4]) / 2.0f;
+                v[e] = (kk + e < a.K) ? t : 0.0f;
+            }
+            f32x4 o;
+            if constexpr (BF16)
+                o = f32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
+                          pack_bf16(v[4 % KB], v[5 % KB]), pack_bf16(v[6 % KB], v[7 % KB])};
+            else
+                o = f32x4{v[0], v[1], v[2], v[3]};
             if (XITEMS % 256 == 0 || tid + j * 256 < XITEMS)
-                *reinterpret_cast<f32x4*>(smem + buf * kBuf + l_off[j]) = v;
+                *reinterpret_cast<f32x4*>(smem + buf * kBuf + l_off[j]) = o;
         } else {
             if (WITEMS % 256 == 0 || tid + (j - NX) * 256 < WITEMS)
                 *reinterpret_cast<f32x4*>(smem + buf * kBuf + l_off[j]) = pre[j];
@@ -147,7 +177,7 @@ fc_mfma_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) load_slot(j, min(1, last));
     __syncthreads();
-    constexpr int NQ = kBK / 8;
+    constexpr int NQ = G / 8;
     constexpr int SPQ = (NSLOT + NQ - 1) / NQ;   // staging slots per k-block of 8
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;
@@ -175,27 +205,39 @@ fc_mfma_kernel(const GemmArgs a) {
                         sW + (((q + 1) * 2 + lh) * BN + (wn * NT + nt) * 32 + li) * 4);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the next fragments' reads above the MFMAs
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
+            if constexpr (BF16) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            xf[cb][mt][s], wf[cb][nt][s], acc[mt * NT + nt], 0, 0, 0);
+                        acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, xf[cb][mt]),
+                            __builtin_bit_cast(bf16x8, wf[cb][nt]), acc[mt * NT + nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                xf[cb][mt][s], wf[cb][nt][s], acc[mt * NT + nt], 0, 0, 0);
+            }
 #pragma unroll
             for (int j = q * SPQ; j < (q + 1) * SPQ && j < NSLOT; ++j) {
                 store_slot(j, buf ^ 1, min(st + 1, last));
                 load_slot(j, st2);
             }
+            if constexpr (!BF16) {
 #pragma unroll
-            for (int s = 2; s < 4; ++s)
+                for (int s = 2; s < 4; ++s)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            xf[cb][mt][s], wf[cb][nt][s], acc[mt * NT + nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                xf[cb][mt][s], wf[cb][nt][s], acc[mt * NT + nt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();   // buffer buf^1 complete, buffer buf free
@@ -219,10 +261,11 @@ fc_mfma_kernel(const GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WBN = BN, int kBK = 32>
+template <int BM, int BN, int WM, int WN, int WBN = BN, int kBK = 32, bool BF16 = false>
 int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
-    constexpr size_t lds = 2 * (size_t)(BM * (kBK + 4) + kBK * BN) * sizeof(float);
-    const bool vec = (a.ldx % 4 == 0) && (a.K % 4 == 0);
+    constexpr int G = BF16 ? kBK / 2 : kBK;
+    constexpr size_t lds = 2 * (size_t)(BM * (G + 4) + G * BN) * sizeof(float);
+    const bool vec = (a.ldx % 4 == 0) && (a.K % (BF16 ? 8 : 4) == 0);
     dim3 grid(dodt::ceil_div(a.M, BM), Npad / BN);
     auto go = [&](auto kernel) -> hipError_t {
         static std::mutex mu;
@@ -241,10 +284,10 @@ int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
         return hipSuccess;
     };
     hipError_t e;
-    if (vec && a.x2) e = go(&fc_mfma_kernel<BM, BN, WM, WN, true, WBN, kBK, true>);
-    else if (vec) e = go(&fc_mfma_kernel<BM, BN, WM, WN, true, WBN, kBK, false>);
-    else if (a.x2) e = go(&fc_mfma_kernel<BM, BN, WM, WN, false, WBN, kBK, true>);
-    else e = go(&fc_mfma_kernel<BM, BN, WM, WN, false, WBN, kBK, false>);
+    if (vec && a.x2) e = go(&fc_mfma_kernel<BM, BN, WM, WN, true, WBN, kBK, true, BF16>);
+    else if (vec) e = go(&fc_mfma_kernel<BM, BN, WM, WN, true, WBN, kBK, false, BF16>);
+    else if (a.x2) e = go(&fc_mfma_kernel<BM, BN, WM, WN, false, WBN, kBK, true, BF16>);
+    else e = go(&fc_mfma_kernel<BM, BN, WM, WN, false, WBN, kBK, false, BF16>);
     DODT_HIP_CHECK(e);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
@@ -255,6 +298,7 @@ int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
 struct dodt_fc {
     dodt_ctx* ctx = nullptr;
     int K = 0, Kp = 0, N = 0, Npad = 0, BN = 0, relu = 0;
+    bool bf16 = false;
     float* d_w = nullptr;
     float* d_b = nullptr;
 };
@@ -263,6 +307,13 @@ extern "C" {
 
 int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int relu,
                    dodt_fc** out) {
+    return dodt_fc_create_ex(ctx, K, N, w, bias, relu ? DODT_FC_RELU : 0, out);
+}
+
+int dodt_fc_create_ex(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int flags,
+                      dodt_fc** out) {
+    const int relu = (flags & DODT_FC_RELU) != 0;
+    const bool bf16 = (flags & DODT_FC_BF16) != 0;
     DODT_REQUIRE(ctx && w && bias && out, "dodt_fc_create: NULL argument");
     DODT_REQUIRE(K >= 1 && N >= 1, "dodt_fc_create: bad sizes");
     dodt_fc* f = new dodt_fc();
@@ -270,16 +321,22 @@ int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bia
     f->K = K;
     f->N = N;
     f->relu = relu;
-    f->Kp = (int)dodt::align_up((size_t)K, kKAlign);
+    f->bf16 = bf16;
+    f->Kp = (int)dodt::align_up((size_t)K, bf16 ? 2 * kKAlign : kKAlign);
     f->BN = (N >= 128) ? 128 : 32;
     f->Npad = (int)dodt::align_up((size_t)N, (size_t)f->BN);
     // blocked weights [n-tile][Kp/8][h][BN][4]; k = 8q + 4h + s
     std::vector<float> blk((size_t)f->Kp * f->Npad, 0.0f), b(f->Npad, 0.0f);
-    const int K8 = f->Kp / 8;
+    //   bf16: [n-tile][Kp/16][h][BN][8] bf16 (k = 16q + 8h + s), in the first half of blk
+    uint16_t* blk16 = reinterpret_cast<uint16_t*>(blk.data());
+    const int kb = bf16 ? 8 : 4, KQ = f->Kp / (2 * kb);
     for (int k = 0; k < K; ++k)
         for (int n = 0; n < N; ++n) {
-            const int q = k / 8, h = (k % 8) / 4, s = k % 4, nt = n / f->BN, nn = n % f->BN;
-            blk[((((size_t)nt * K8 + q) * 2 + h) * f->BN + nn) * 4 + s] = w[(size_t)k * N + n];
+            const int q = k / (2 * kb), h = (k % (2 * kb)) / kb, s = k % kb;
+            const int nt = n / f->BN, nn = n % f->BN;
+            const size_t idx = ((((size_t)nt * KQ + q) * 2 + h) * f->BN + nn) * kb + s;
+            if (bf16) blk16[idx] = dodt::float_to_bf16(w[(size_t)k * N + n]);
+            else blk[idx] = w[(size_t)k * N + n];
         }
     for (int n = 0; n < N; ++n) b[n] = bias[n];
     hipError_t e1 = hipMalloc(&f->d_w, blk.size() * sizeof(float));
@@ -316,6 +373,10 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
     a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = ldy; a.relu = f->relu;
     a.d_m = d_m;
     hipStream_t s = (ctx ? ctx : f->ctx)->stream;
+    if (f->bf16) {
+        if (f->BN == 128) return launch_fc<64, 128, 2, 2, 128, 128, true>(s, a, f->Npad);
+        return launch_fc<128, 32, 4, 1, 32, 64, true>(s, a, f->Npad);
+    }
     if (f->BN == 128) {
         // tile shapes measured at the heads' sizes (M = 1024, N = K = 2048): 64x128 with a
         // 64-deep stage 97 TFLOP/s; 64x64 tiles and 32-deep stages within 3 % of it; 128x128

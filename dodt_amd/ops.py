@@ -161,16 +161,21 @@ class FullyConnected(object):
     """y = act(x w + b) on the device (dodt_fc_*).  w (K,N) row-major, the layout of the
     TF variable (conv kernels reshaped (kh*kw*cin, cout))."""
 
-    def __init__(self, ctx, w, b, relu):
+    def __init__(self, ctx, w, b, relu, dtype='f32'):
+        """dtype 'bf16': bf16 MFMA, fp32 accumulate (DODT_FC_BF16)."""
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
         w = np.ascontiguousarray(w, dtype=np.float32)
         b = np.ascontiguousarray(b, dtype=np.float32)
         if w.ndim != 2 or b.shape != (w.shape[1],):
             raise ValueError('weights must be (K,N) and bias (N,)')
         self.ctx, self.K, self.N = ctx, int(w.shape[0]), int(w.shape[1])
         h = C.c_void_p()
-        _lib.check(ctx.lib.dodt_fc_create(ctx.handle, self.K, self.N, w.ctypes.data_as(C.c_void_p),
-                                          b.ctypes.data_as(C.c_void_p), int(bool(relu)),
-                                          C.byref(h)), 'dodt_fc_create')
+        flags = (_lib.FC_RELU if relu else 0) | (_lib.FC_BF16 if dtype == 'bf16' else 0)
+        _lib.check(ctx.lib.dodt_fc_create_ex(ctx.handle, self.K, self.N,
+                                             w.ctypes.data_as(C.c_void_p),
+                                             b.ctypes.data_as(C.c_void_p), flags, C.byref(h)),
+                   'dodt_fc_create_ex')
         self.handle = h
 
     def forward(self, d_x, M, d_y, ldx=None, ldy=None, d_x2=None, d_m=None, ctx=None):

@@ -45,7 +45,7 @@ class FramePairPipeline(object):
                  tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
                  n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None,
                  pairs_per_step=1, side_streams=None, head_params=None, conv_dtype='f32',
-                 reuse_streams_of=None):
+                 head_dtype='f32', reuse_streams_of=None):
         self.ctx = ctx
         self.cfg = cfg
         self.p2 = np.asarray(p2, dtype=np.float64)
@@ -97,9 +97,10 @@ class FramePairPipeline(object):
         N, P = self.n_all, self.P
         self.rpn_head = self.avod_head = self.corr_head = None
         if head_params is not None:
-            self.rpn_head = AnchorPredictor(ctx, head_params['rpn'])
-            self.avod_head = EarlyFusionFcLayers(ctx, head_params['avod'])
-            self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'], outputs=('off_out',))
+            self.rpn_head = AnchorPredictor(ctx, head_params['rpn'], dtype=head_dtype)
+            self.avod_head = EarlyFusionFcLayers(ctx, head_params['avod'], dtype=head_dtype)
+            self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'], outputs=('off_out',),
+                                                 dtype=head_dtype)
             self.head_scratch = [dict(rpn=self.rpn_head.make_scratch(N),
                                       fc=self.avod_head.make_scratch(P),
                                       corr_map=ctx.empty((self.bev_h, self.bev_w, CORR_CH), f32))

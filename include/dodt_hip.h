@@ -239,6 +239,13 @@ int dodt_correlation(dodt_ctx* ctx, const float* d_a, const float* d_b, int H, i
 typedef struct dodt_fc dodt_fc;
 int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int relu,
                    dodt_fc** out);
+/* flags: DODT_FC_RELU; DODT_FC_BF16 = x rounded to bf16 on load, weights stored as bf16,
+ * bf16 MFMA with fp32 accumulation, bias + activation and the output in fp32 (the heads'
+ * counterpart of DODT_EXTRACTOR_BF16; not the reference's arithmetic). */
+#define DODT_FC_RELU 1
+#define DODT_FC_BF16 2
+int dodt_fc_create_ex(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int flags,
+                      dodt_fc** out);
 int dodt_fc_destroy(dodt_fc* fc);
 int dodt_fc_forward(dodt_fc* fc, dodt_ctx* ctx, const float* d_x, const float* d_x2, int ldx,
                     int M, const int32_t* d_m, float* d_y, int ldy);

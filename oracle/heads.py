@@ -10,8 +10,13 @@ fp32 summation order (float64 accumulation here, tolerance 1e-4 * scale in the t
 import numpy as np
 
 
-def fc(x, w, b, relu=True):
-    """slim.fully_connected / 1x1 slim.conv2d: x (M,K) float32, w (K,N), b (N,)."""
+def fc(x, w, b, relu=True, dtype='f32'):
+    """slim.fully_connected / 1x1 slim.conv2d: x (M,K) float32, w (K,N), b (N,).
+    dtype 'bf16' restates the device's DODT_FC_BF16 scheme: x and w rounded to bf16 (nearest
+    even), exact products, wide accumulation, fp32 bias / activation / output."""
+    if dtype == 'bf16':
+        from oracle import tfops
+        x, w = tfops.round_bf16(x), tfops.round_bf16(w)
     y = (x.astype(np.float64) @ w.astype(np.float64) + b.astype(np.float64)).astype(np.float32)
     return np.maximum(y, np.float32(0)) if relu else y
 

@@ -81,6 +81,28 @@ def test_fully_connected_matches_oracle(ctx, M, K, N, relu, fuse):
     fc.close()
 
 
+@pytest.mark.parametrize('M,K,N,relu,fuse', [
+    (300, 9, 512, True, True), (1024, 1568, 2048, True, True), (1000, 2048, 10, False, False),
+    (513, 1225, 2048, True, False), (777, 256, 6, False, False), (64, 40, 128, True, False)])
+def test_fully_connected_bf16_matches_its_oracle(ctx, M, K, N, relu, fuse):
+    """DODT_FC_BF16: same rounding points as the oracle's restatement, so only the fp32
+    summation order differs: 1e-4 of the output scale like the fp32 layers.  Against the fp32
+    arithmetic of the reference the bf16 layer is ~3e-3 off (stated, not a parity claim)."""
+    rng = np.random.default_rng(M + K + N + 1)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    x2 = rng.normal(size=(M, K)).astype(np.float32) if fuse else None
+    w = rng.normal(0, np.sqrt(2.0 / K), size=(K, N)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=N).astype(np.float32)
+    fc = ops.FullyConnected(ctx, w, b, relu, dtype='bf16')
+    d_y = ctx.array(np.full((M, N), np.nan, np.float32))
+    fc.forward(ctx.array(x), M, d_y, d_x2=None if x2 is None else ctx.array(x2))
+    xin = oheads.mean_fusion(x, x2) if fuse else x
+    got = d_y.download()
+    _close(got, oheads.fc(xin, w, b, relu, dtype='bf16'))
+    _close(got, oheads.fc(xin, w, b, relu), 1e-2)
+    fc.close()
+
+
 def test_fully_connected_strides_and_device_row_count(ctx):
     rng = np.random.default_rng(8)
     M, K, N, ldx, ldy = 200, 256, 256, 512, 300
