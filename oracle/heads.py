@@ -27,7 +27,7 @@ def mean_fusion(a, b):
     return ((a.astype(np.float32) + b.astype(np.float32)) / np.float32(2.0)).astype(np.float32)
 
 
-def rpn_anchor_predictor(bev_roi, img_roi, p):
+def rpn_anchor_predictor(bev_roi, img_roi, p, dtype='f32'):
     """dt_rpn_model.py:445-537.  bev_roi, img_roi (A,3,3,1); p[name] = dict(w, b) with the TF
     shapes: *_fc6 (3,3,1,256) VALID conv = FC over the flattened 3x3 crop, *_fc7
     (1,1,256,256), cls_fc8 (1,1,256,2), reg_fc8 (1,1,256,6).  -> objectness (A,2),
@@ -38,25 +38,25 @@ def rpn_anchor_predictor(bev_roi, img_roi, p):
         h = x
         for li, relu in (('fc6', True), ('fc7', True), ('fc8', False)):
             q = p['%s_%s' % (br, li)]
-            h = fc(h, q['w'].reshape(-1, q['w'].shape[-1]), q['b'], relu)
+            h = fc(h, q['w'].reshape(-1, q['w'].shape[-1]), q['b'], relu, dtype)
         out.append(h)
     return out[0], out[1]
 
 
-def fusion_fc_early(bev_rois, img_rois, p):
+def fusion_fc_early(bev_rois, img_rois, p, dtype='f32'):
     """fusion_fc_layers.py:136-180 (early fusion, 'mean'), box_4c: no angle output
     (avod_fc_layer_utils.py:11-17).  rois (P,7,7,32) -> cls logits (P,2), offsets (P,10)."""
     h = mean_fusion(bev_rois, img_rois).reshape(len(bev_rois), -1)
     for name in ('fc6', 'fc7', 'fc8'):
-        h = fc(h, p[name]['w'], p[name]['b'], True)
-    return (fc(h, p['cls_out']['w'], p['cls_out']['b'], False),
-            fc(h, p['off_out']['w'], p['off_out']['b'], False))
+        h = fc(h, p[name]['w'], p[name]['b'], True, dtype)
+    return (fc(h, p['cls_out']['w'], p['cls_out']['b'], False, dtype),
+            fc(h, p['off_out']['w'], p['off_out']['b'], False, dtype))
 
 
-def corr_fc_early(corr_rois, p):
+def corr_fc_early(corr_rois, p, dtype='f32'):
     """avod_corr_layers_builder.py:126-169: flatten the (P,7,7,25) correlation crops, the
     same fc6..fc8 stack, off_out -> (P,3) [dx, dz, dry]."""
     h = corr_rois.reshape(len(corr_rois), -1).astype(np.float32)
     for name in ('fc6', 'fc7', 'fc8'):
-        h = fc(h, p[name]['w'], p[name]['b'], True)
-    return fc(h, p['off_out']['w'], p['off_out']['b'], False)
+        h = fc(h, p[name]['w'], p[name]['b'], True, dtype)
+    return fc(h, p['off_out']['w'], p['off_out']['b'], False, dtype)
