@@ -206,6 +206,7 @@ def main():
             conv_ms += c.timer_stop() / reps
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
                    flops=pipe.flops_per_step(), head_gflop=pipe.head_flops_per_step() / 1e9,
+                   conv_bytes=pipe.conv_bytes_per_step(),
                    anchors=list(pipe.last_anchor_counts), steps=steps)
         pipe.close()
         return res
@@ -232,24 +233,35 @@ def main():
                'runs': [short(other, 'f32')] + ([short('bf16', 'bf16')] if computed else [])}
     flops = m['flops']
     achieved = flops / (conv_ms * 1e-3) / 1e12
-    # TFLOP/s, dense MFMA peak of the conv dtype, MI355X_MICROARCH.md chip table
-    peak = 157.3 if args.conv_dtype == 'f32' else 2500.0
     # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
     # figure comes from the rocprofv3 --pmc passes over this same command (profiles/)
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, 'profiles', 'r1_conv_traffic.json')
+    tj = os.path.join(ROOT, 'profiles', 'r1_conv_traffic.json' if args.conv_dtype == 'f32'
+                      else 'r1bf16_conv_traffic.json')
     if os.path.exists(tj):
         t = json.load(open(tj))
         traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
         traffic_src = t['source']
-    roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                    frac=round(achieved / peak, 4), traffic=traffic, traffic_unit='bytes/launch',
-                    traffic_source=traffic_src,
-                    kernel='conv3x3_mfma_kernel (30 launches per step) + 2 first-layer launches',
-                    launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
-                    launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),
-                    measured='HIP events, each net alone on its stream, %d reps after the '
-                             'timed region' % reps)
+    common = dict(traffic=traffic, traffic_unit='bytes/launch', traffic_source=traffic_src,
+                  kernel='conv3x3_mfma_kernel (30 launches per step) + 2 first-layer launches',
+                  launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
+                  algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
+                  launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),
+                  measured='HIP events, each net alone on its stream, %d reps after the '
+                           'timed region' % reps)
+    if args.conv_dtype == 'f32':
+        # fp32 MFMA: 157.3 TFLOP/s dense (MI355X_MICROARCH.md chip table); every layer is
+        # MFMA-bound at fp32
+        roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=157.3, unit='TFLOP/s',
+                        frac=round(achieved / 157.3, 4), **common)
+    else:
+        # bf16 MFMA (2.5 PFLOP/s) makes the stacks 16x cheaper in matrix time than in fp32:
+        # they are bound by moving the maps (HBM ~8 TB/s), which is what is priced here;
+        # the matrix-pipe fraction is given beside it
+        gbs = m['conv_bytes'] / (conv_ms * 1e-3) / 1e9
+        roofline = dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s',
+                        frac=round(gbs / 8000.0, 4), mfma_tflops=round(achieved, 2),
+                        mfma_frac_of_2500=round(achieved / 2500.0, 4), **common)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

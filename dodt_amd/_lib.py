@@ -92,6 +92,7 @@ SIGNATURES = {
                                             C.POINTER(_i), C.POINTER(_i),
                                             C.POINTER(_i)]),
     'dodt_extractor_flops': (_d, [_vp]),
+    'dodt_extractor_bytes': (_d, [_vp]),
     'dodt_crop_and_resize': (_i, [_vp, _pf, _i, _i, _i, _pf, _i, _pi32, _i, _i,
                                   _pf]),
     'dodt_correlation': (_i, [_vp, _pf, _pf, _i, _i, _i, _i, _i, _i, _pf]),

@@ -95,6 +95,10 @@ class _VggPyr(object):
     def flops(self):
         return self._ctx.lib.dodt_extractor_flops(self._handle)
 
+    def bytes(self):
+        """Algorithmic HBM bytes of one forward."""
+        return self._ctx.lib.dodt_extractor_bytes(self._handle)
+
     def activation(self, name):
         h, w, c = C.c_int(), C.c_int(), C.c_int()
         lib = self._ctx.lib

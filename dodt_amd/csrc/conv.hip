@@ -692,6 +692,25 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
     return DODT_OK;
 }
 
+double dodt_extractor_bytes(const dodt_extractor* ex) {
+    if (!ex) return 0.0;
+    // algorithmic HBM bytes of one forward: every layer reads its input map and its weights
+    // once and writes its output map once (pooled copies and the bottleneck included)
+    double b = 0.0;
+    for (const Layer& l : ex->layers) {
+        const double in_e = ex->buf[l.src].bf16 ? 2.0 : 4.0;
+        const double out_e = ex->buf[l.dst].bf16 ? 2.0 : 4.0;
+        const double w_e = (ex->bf16 && &l != &ex->layers[0]) ? 2.0 : 4.0;
+        const double oh = l.deconv ? 2.0 * l.H : l.H, ow = l.deconv ? 2.0 * l.W : l.W;
+        b += ex->batch * ((double)l.H * l.W * l.real_cin * in_e + oh * ow * l.Cout * out_e) +
+             9.0 * l.real_cin * l.Cout * w_e;
+        if (l.name == "conv1_2" || l.name == "conv2_2" || l.name == "conv3_3")
+            b += ex->batch * (oh / 2) * (ow / 2) * l.Cout * out_e;
+    }
+    b += (double)ex->batch * ex->in_h * ex->in_w * 4.0;   // bottleneck map
+    return b;
+}
+
 double dodt_extractor_flops(const dodt_extractor* ex) {
     if (!ex) return 0.0;
     double f = 0.0;  // 2*M*N*K per layer; transposed convs counted on input pixels

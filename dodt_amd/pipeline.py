@@ -356,6 +356,10 @@ class FramePairPipeline(object):
         """Conv stacks only (the roofline kernel); see head_flops_per_step."""
         return self.bev_net.flops() + self.img_net.flops()
 
+    def conv_bytes_per_step(self):
+        """Algorithmic HBM bytes of the two conv stacks per step."""
+        return self.bev_net.bytes() + self.img_net.bytes()
+
     def head_flops_per_step(self, anchor_counts=None):
         if self.rpn_head is None:
             return 0.0

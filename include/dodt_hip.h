@@ -208,6 +208,8 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
                                    int* h, int* w, int* c);
 /* FLOPs of one forward call (2*M*N*K summed over conv layers, all frames). */
 double dodt_extractor_flops(const dodt_extractor* ex);
+/* Algorithmic HBM bytes of one forward (each map and the weights read / written once). */
+double dodt_extractor_bytes(const dodt_extractor* ex);
 
 /* ---- a11: ROI crop ------------------------------------------------------------------
  * tf.image.crop_and_resize(image, boxes, box_ind=0, crop_size) call sites

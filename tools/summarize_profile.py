@@ -23,7 +23,8 @@ def one(pattern):
 stats = one('%s_stats/**/*kernel_stats.csv' % tag)
 shutil.copy(stats, os.path.join(out, '%s_kernel_stats.csv' % tag))
 rows = list(csv.DictReader(open(stats)))
-lines = ['# %s: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline' % tag, '',
+extra = ' '.join(sys.argv[2:])
+lines = ['# %s: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-alt %s' % (tag, extra), '',
          '| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
 conv_ns = conv_calls = 0
 for r in rows[:24]:
