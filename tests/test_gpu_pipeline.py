@@ -135,3 +135,22 @@ def test_pair_is_repeatable_and_independent(setup):
     _run(ctx, pipe, seq=2, frames=(1, 3))
     _run(ctx, pipe, seq=1, frames=(4, 6))
     assert np.array_equal(r1, pipe.d_records.download())
+
+
+def test_empty_cloud_gives_empty_frame_and_leaves_the_other_alone(setup):
+    """A frame without a single LiDAR return (the reference raises inside voxelize_2d on the
+    empty density slice, wavedata/.../voxel_grid_2d.py:110-125): here that frame keeps no
+    anchor and reports no detection, and the pair's other frame is untouched."""
+    ctx, pipe = setup
+    pts, imgs, heads, counts = _run(ctx, pipe, seq=8, frames=(0, 2))
+    full = pipe.d_records.download().copy()
+    d_heads = [{k: ctx.array(v) for k, v in h.items()} for h in heads]
+    pipe.run([ctx.array(pts[0]), ctx.empty((1, 4), np.float32)], [len(pts[0]), 0],
+             [ctx.array(i) for i in imgs], d_heads)
+    pipe.finish()
+    ctx.sync()
+    assert pipe.last_anchor_counts[0] == counts[0] and pipe.last_anchor_counts[1] == 0
+    rec = pipe.d_records.download()
+    cnt = pipe.d_rec_counts.download().reshape(-1)
+    assert cnt[1] == 0 and not rec[0, 1].any()
+    assert np.array_equal(rec[0, 0], full[0, 0])
