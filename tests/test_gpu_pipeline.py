@@ -154,3 +154,29 @@ def test_empty_cloud_gives_empty_frame_and_leaves_the_other_alone(setup):
     cnt = pipe.d_rec_counts.download().reshape(-1)
     assert cnt[1] == 0 and not rec[0, 1].any()
     assert np.array_equal(rec[0, 0], full[0, 0])
+
+
+def test_dense_scene_300k_points_4096_proposals():
+    """BASELINE.json configs[4]'s shape (300k points per frame, 4096 proposals): voxeliser,
+    anchor filter, both NMS stages and the decoders against the oracle, indices exact."""
+    ctx = device.default_context()
+    pipe = FramePairPipeline(ctx, C, n_points_max=300000, rpn_nms_size=4096)
+    pts, imgs, heads, counts = _run(ctx, pipe, seq=9, frames=(0, 3), n_points=300000)   # tau = 3
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    for f in range(2):
+        b = pipe.fr[f]
+        inp = opipe.frame_inputs(pts[f], C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                 synth.IMAGE_WH)
+        A = len(inp['keep'])
+        assert counts[f] == A
+        assert np.array_equal(b['keep'].download()[:A], inp['keep'])
+        assert np.array_equal(pipe.d_bev_in[f].download(), inp['bev'])
+        want = opipe.frame_detections(inp, heads[f], C, synth.P2, synth.IMAGE_WH, pipe.P,
+                                      frame_mark=f)
+        n_top = int(b['top_count'].download()[0])
+        assert n_top == len(want['top_idx']) and n_top > 1024
+        assert np.array_equal(b['top_idx'].download()[:n_top], want['top_idx'])
+        n_det = int(b['det_count'].download()[0])
+        assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
+        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-5, atol=1e-4)
+    pipe.close()
