@@ -1,4 +1,7 @@
-// 3x3 convolution / 3x3 stride-2 transposed convolution on the fp32 MFMA of gfx950.
+// 3x3 convolution / 3x3 stride-2 transposed convolution on the MFMA of gfx950: fp32
+// (v_mfma_f32_32x32x2_f32, the reference's arithmetic, described below) or, template
+// parameter BF16, bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16 over CB16 bf16
+// maps; same tiling, same byte geometry of every LDS image).
 //
 // Implicit GEMM, M = output pixels, N = output channels, K = 9 * Cin, computed
 // with v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain per output).

@@ -25,16 +25,12 @@ constexpr int kPS = kCH + 4;  // LDS floats per pixel (16 + 4 pad: conflict-free
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// GW = 2r+1 and S2 may be fixed at compile time; the runtime form <0,0> is the one in use
-// (a fully unrolled displacement loop makes hipcc hoist all 100 LDS reads and spill).
-template <int GW, int S2>
+// The displacement loop stays a runtime loop: fully unrolled (compile-time r, s2) hipcc hoists
+// all 100 LDS reads of a pass and spills (measured 528 us against 101 us for this form).
 __global__ void __launch_bounds__(256, 3)
 correlation_kernel(const float* __restrict__ A, const float* __restrict__ B, int H, int W,
-                   int d, int pad, int s2_rt, int r_rt, int OH, int OW,
-                   float* __restrict__ out) {
+                   int d, int pad, int s2, int r, int OH, int OW, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int s2 = GW ? S2 : s2_rt;
-    const int r = GW ? (GW - 1) / 2 : r_rt;
     const int R = r * s2;              // neighbourhood radius in pixels
     const int PT = kT + 2 * R;         // patch edge
     const int gw = 2 * r + 1, K = gw * gw;
@@ -51,9 +47,9 @@ correlation_kernel(const float* __restrict__ A, const float* __restrict__ B, int
         a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a_in) a[q] = *reinterpret_cast<const f32x4*>(A + ((size_t)ay * W + ax) * kC + q * 4);
     }
-    float res[GW ? GW * GW : 32];   // generic form: host checks K <= 32
+    float res[32];   // host checks K <= 32
 #pragma unroll
-    for (int k = 0; k < (GW ? GW * GW : 32); ++k) res[k] = 0.0f;
+    for (int k = 0; k < 32; ++k) res[k] = 0.0f;
 #pragma unroll
     for (int pass = 0; pass < kC / kCH; ++pass) {
         if (pass) __syncthreads();     // everyone is done reading the previous channels
@@ -70,8 +66,7 @@ correlation_kernel(const float* __restrict__ A, const float* __restrict__ B, int
         }
         __syncthreads();
         // channel sums stay one sequential float32 chain per output, c = 0 .. 31
-#pragma unroll
-        for (int k = 0; k < (GW ? GW * GW : K); ++k) {
+        for (int k = 0; k < K; ++k) {
             const int s2p = (k / gw - r) * s2, s2o = (k % gw - r) * s2;
             const float* b = smem + ((ly + R + s2p) * PT + (lx + R + s2o)) * kPS;
             float sum = res[k];
@@ -85,15 +80,11 @@ correlation_kernel(const float* __restrict__ A, const float* __restrict__ B, int
                 sum += av[3] * bv[3];
             }
             res[k] = sum;
-            // one displacement's LDS reads at a time: hoisting all of them costs 400 VGPRs
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int k = 0; k < (GW ? GW * GW : K); ++k) res[k] = res[k] / (float)kC;
+    for (int k = 0; k < K; ++k) res[k] = res[k] / (float)kC;
     __syncthreads();   // the patch is dead: reuse LDS as the [pixel][K] output tile
-#pragma unroll
-    for (int k = 0; k < (GW ? GW * GW : K); ++k) smem[tid * K + k] = res[k];
+    for (int k = 0; k < K; ++k) smem[tid * K + k] = res[k];
     __syncthreads();
     // rows of the tile are contiguous in the output: kT * K floats each
     for (int t = tid; t < kT * kT * K; t += 256) {
@@ -123,11 +114,15 @@ extern "C" int dodt_correlation(dodt_ctx* ctx, const float* d_a, const float* d_
     const size_t lds_out = (size_t)kT * kT * K * sizeof(float);
     if (lds < lds_out) lds = lds_out;
     DODT_REQUIRE(lds <= 160 * 1024, "dodt_correlation: neighbourhood does not fit LDS");
-    void (*kernel)(const float*, const float*, int, int, int, int, int, int, int, int, float*) =
-        &correlation_kernel<0, 0>;   // measured: 101 us at (700,800,32), 2 TB/s of HBM traffic
-    DODT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kernel, dim3(dodt::ceil_div(OW, kT), dodt::ceil_div(OH, kT)), dim3(256),
+    // measured: 101 us at (700,800,32), 2 TB/s of HBM traffic
+    static bool prepared = false;
+    if (!prepared) {
+        DODT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&correlation_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        prepared = true;
+    }
+    hipLaunchKernelGGL(correlation_kernel, dim3(dodt::ceil_div(OW, kT), dodt::ceil_div(OH, kT)), dim3(256),
                        lds, ctx->stream, d_a, d_b, H, W, max_displacement, pad, stride_2, r, OH,
                        OW, d_out);
     DODT_LAUNCH_CHECK();
