@@ -149,9 +149,19 @@ def main():
 
         state = {'n': 0, 'par': 0}
 
+        fake = os.environ.get('DODT_BENCH_FAKE_GATHER') == '1'   # rehearsal of the N > 1 stream
+        side = torch.cuda.Stream() if fake else None               # pattern on one GPU
+
         def gather(par):
             if world > 1:
                 sharding.all_gather_records(dist, rec[par], cnt[par], gathered, gathered_cnt)
+            elif fake:     # like ProcessGroupNCCL: own stream, joined with the current one
+                cur_s = torch.cuda.current_stream()
+                side.wait_stream(cur_s)
+                with torch.cuda.stream(side):
+                    gathered[:pps].copy_(rec[par])
+                    gathered_cnt[:pps].copy_(cnt[par])
+                cur_s.wait_stream(side)
 
         def step(i):
             p = batches[i % n_batches]
@@ -204,7 +214,18 @@ def main():
             for _ in range(reps):
                 net.forward_device(None, f, b)
             conv_ms += c.timer_stop() / reps
+        # both nets side by side, as in the timed steps (but nothing else on the GPU)
+        ctx.sync()
+        pipe.img_ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            pipe.img_ctx.wait_for(ctx)
+            pipe.bev_net.forward_device(None, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck'])
+            pipe.img_net.forward_device(None, pipe.feat[0]['img_feat'], pipe.feat[0]['img_bneck'])
+            ctx.wait_for(pipe.img_ctx)
+        both_ms = ctx.timer_stop() / reps
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
+                   both_ms=both_ms,
                    flops=pipe.flops_per_step(), head_gflop=pipe.head_flops_per_step() / 1e9,
                    conv_bytes=pipe.conv_bytes_per_step(),
                    anchors=list(pipe.last_anchor_counts), steps=steps)
@@ -247,6 +268,8 @@ def main():
                   launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
                   algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
                   launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),
+                  side_by_side_ms=round(m['both_ms'], 4),
+                  side_by_side_tflops=round(flops / (m['both_ms'] * 1e-3) / 1e12, 2),
                   measured='HIP events, each net alone on its stream, %d reps after the '
                            'timed region' % reps)
     if args.conv_dtype == 'f32':
