@@ -67,7 +67,7 @@ const std::vector<KernelVariant>& variants() {
 }
 
 // smallest padded pixel count wins; ties go to the larger output tile
-int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16) {
+int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int batch, int num_cus) {
     const auto& vs = variants();
     const bool small = Cin < dodt::kCK;
     int best = -1;
@@ -82,8 +82,27 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16) {
         // the chunk pipeline needs >= 2 chunks (8 channels fp32, 16 channels bf16) per item
         if (small ? (Cin != v.CK || Cout != 32) : (Cin % v.CK != 0 || Cin < 32)) continue;
         const double padded = (double)dodt::ceil_div(H, v.TH) * v.TH * dodt::ceil_div(W, v.TW) * v.TW;
-        // mild preference for more work per staged byte
-        const double cost = padded * (1.0 + 0.04 / v.MTB + 1.0 / v.BN);
+        double cost;
+        // which model: measured.  fp32: the padded-pixel rule (the round model's choices run a
+        // lone net 9 % faster but the frame-pair pipeline 4 % slower); bf16: the round model
+        // (stacks 15 % faster alone, pipeline 4-6 % faster).  DODT_CONV_ROUND_MODEL=0/1 forces.
+        static const int force = getenv("DODT_CONV_ROUND_MODEL") ? atoi(getenv("DODT_CONV_ROUND_MODEL")) : -1;
+        const bool model = force >= 0 ? force != 0 : bf16;
+        if (!model || small) {
+            // padded pixels, mild preference for more work per staged byte
+            cost = padded * (1.0 + 0.04 / v.MTB + 1.0 / v.BN);
+        } else {
+            // round model: workgroups sharing a CU share its matrix pipe, so a layer takes
+            // ceil(items / CUs) item times; an item = its 32x32 MFMA tiles over the variant's
+            // in-tile efficiency (2x2 tiles per wave 1.0, 2 tiles 0.9, 1 tile 0.8)
+            const double items = (double)dodt::ceil_div(H, v.TH) * dodt::ceil_div(W, v.TW) * batch *
+                                 (Cout / v.BN);
+            const int wave_tiles = deconv ? 4 * (v.BN / 32 / v.WN)
+                                          : (v.MTB / v.WM) * (v.BN / 32 / v.WN);
+            const double eff = wave_tiles >= 4 ? 1.0 : wave_tiles >= 2 ? 0.9 : 0.8;
+            const double units = (double)(v.TW * v.TH / 32) * (v.BN / 32);
+            cost = std::ceil(items / num_cus) * units / eff;
+        }
         if (cost < best_cost) { best_cost = cost; best = (int)i; }
     }
     return best;
@@ -423,7 +442,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         Layer l;
         l.name = name; l.deconv = deconv; l.H = h; l.W = w; l.Cin = cin; l.Cout = cout;
         l.src = src; l.src_coff = src_coff; l.dst = dst; l.dst_coff = dst_coff;
-        l.variant = pick_variant(deconv, h, w, cin, cout, bf16);
+        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, batch, ctx->num_cus);
         l.real_cin = cin;
         ex->layers.push_back(l);
     };
