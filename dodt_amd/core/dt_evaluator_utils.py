@@ -1,0 +1,159 @@
+"""Temporal module on the host (the "M" of S+T+M): associate the
+detections of a keyframe pair and fill in the frames between them.
+
+Mirrors avod/core/dt_evaluator_utils.py:212-362 (interpolate_non_keyframe_predicitons,
+interpolate_trajectory).  Input: the 17-column records of one pair as the device writes them
+(FramePairPipeline.d_records, gathered across ranks by dodt_amd.sharding).  The reference
+scores candidate matches with a 3-D IoU whose base overlap is rasterised at 1 cm with PIL
+(wavedata/.../evaluation.py:182-261); here the overlap of the two rotated rectangles is
+computed exactly by polygon clipping ("an exact polygon 3-D IoU") -- the
+association only uses argmax and `> 0`, and reproduces the reference's outputs on the golden
+cases (tests/test_temporal.py).  `recover(frame_index, rows)` stands for the reference's
+recovery_coordinate (OXTS ego-motion, dataset layer, out of scope); None keeps keyframe-0
+coordinates.
+"""
+import numpy as np
+
+
+def _rect(b):
+    """(4,2) corners (x,z) of the base of [x,y,z,l,w,h,ry], counter-clockwise or clockwise."""
+    c, s = np.cos(b[6]), np.sin(b[6])
+    xc = b[3] / 2 * np.array([1, 1, -1, -1])
+    zc = b[4] / 2 * np.array([1, -1, -1, 1])
+    return np.stack([c * xc + s * zc + b[0], -s * xc + c * zc + b[2]], 1)
+
+
+def _clip(poly, a, b):
+    """Sutherland-Hodgman: keep the part of `poly` on the inner side of edge a->b."""
+    out = []
+    n = len(poly)
+    if n == 0:
+        return poly
+    d = b - a
+    side = d[0] * (poly[:, 1] - a[1]) - d[1] * (poly[:, 0] - a[0])
+    for i in range(n):
+        j = (i + 1) % n
+        pi, pj, si, sj = poly[i], poly[j], side[i], side[j]
+        if si >= 0:
+            out.append(pi)
+        if (si >= 0) != (sj >= 0):
+            t = si / (si - sj)
+            out.append(pi + t * (pj - pi))
+    return np.asarray(out).reshape(-1, 2)
+
+
+def _area(poly):
+    if len(poly) < 3:
+        return 0.0
+    x, z = poly[:, 0], poly[:, 1]
+    return 0.5 * abs(np.dot(x, np.roll(z, -1)) - np.dot(z, np.roll(x, -1)))
+
+
+def base_intersection(box, other):
+    """Exact overlap area of the two boxes' bases (rotated rectangles in the xz plane)."""
+    p, q = _rect(box), _rect(other)
+    e0, e1 = q[1] - q[0], q[2] - q[1]
+    if e0[0] * e1[1] - e0[1] * e1[0] < 0:          # make the clip polygon counter-clockwise
+        q = q[::-1]
+    for i in range(4):
+        p = _clip(p, q[i], q[(i + 1) % 4])
+        if len(p) == 0:
+            return 0.0
+    return _area(p)
+
+
+def three_d_iou(box, boxes):
+    """box (7,), boxes (n,7), both [x,y,z,l,w,h,ry] (y = bottom, down positive) -> (n,) IoU."""
+    boxes = np.atleast_2d(np.asarray(boxes, dtype=np.float64))
+    box = np.asarray(box, dtype=np.float64)
+    diag = np.sqrt((box[3:6] ** 2).sum()) / 2
+    diags = np.sqrt((boxes[:, 3:6] ** 2).sum(1)) / 2
+    dist = np.sqrt(((boxes[:, 0:3] - box[0:3]) ** 2).sum(1))
+    iou = np.zeros(len(boxes))
+    for i in np.nonzero(diag + diags >= dist)[0]:
+        o = boxes[i]
+        h_int = max(0.0, min(box[1], o[1]) - max(box[1] - box[5], o[1] - o[5]))
+        inter = h_int * base_intersection(box, o)
+        iou[i] = inter / (np.prod(box[3:6]) + np.prod(o[3:6]) - inter)
+    return iou
+
+
+def _fill(track_a, track_b, num):
+    """One trajectory over num frames (dt_evaluator_utils.py:296-362); None = no object."""
+    if track_a is not None and track_b is not None:
+        a, b = track_a[:-4].copy(), track_b[:-4].copy()
+        score = max(a[7], b[7])
+        steps = (b[[0, 2, 6]] - a[[0, 2, 6]])
+        out = [a]
+        for i in range(num - 2):
+            o = a.copy()
+            o[[0, 2, 6]] += steps * (i + 1.0) / (num - 1)
+            o[7] = score
+            out.append(o)
+        b[7] = score
+        return out + [b]
+    only, first = (track_b, False) if track_a is None else (track_a, True)
+    offsets, o = only[-4:-1], only[:-4].copy()
+    d = np.sqrt(offsets[0] ** 2 + offsets[1] ** 2)
+    near = d <= o[4] / 2
+    dx, dz = d * np.cos(o[6]), d * np.sin(o[6])
+    out = []
+    if first:       # seen in keyframe 0 only: moves on, or dies after half of the frames
+        out.append(o)
+        for i in range(num - 1):
+            if near:
+                n = o.copy()
+                n[0] += dx * (i + 1.0) / (num - 1)
+                n[2] += dz * (i + 1.0) / (num - 1)
+                out.append(n)
+            else:
+                out.append(None if i >= num / 2 else o.copy())
+    else:           # seen in keyframe 1 only: traced back, or born after half of the frames
+        for i in range(num - 1):
+            if near:
+                n = o.copy()
+                n[0] -= dx * (num - i - 2) / (num - 1)
+                n[2] -= dz * (num - i - 2) / (num - 1)
+                out.append(n)
+            else:
+                out.append(None if i <= num / 2 else o.copy())
+        out.append(o)
+    return out
+
+
+def interpolate_non_keyframe_predictions(predictions, n_frames, threshold, recover=None):
+    """predictions (n,17): box_3d(7), score, type, shifted box(7), frame mark (0/1).
+    n_frames: frames from keyframe 0 to keyframe 1 inclusive (tau + 1; 1 = a lone frame).
+    Returns n_frames arrays (k,13), like the reference (columns [:-4] of the records)."""
+    p = np.asarray(predictions, dtype=np.float64).reshape(-1, 17)
+    rec = recover or (lambda i, rows: rows)
+    kept = [p[(p[:, -1] == i) & (p[:, 7] > threshold)] for i in range(min(n_frames, 2))]
+    if n_frames == 1:
+        return [kept[0][:, :-4]]
+    if n_frames == 2:
+        return [kept[0][:, :-4], rec(1, kept[1][:, :-4])]
+    k0, k1 = kept
+    if len(k0) == 0 and len(k1) == 0:      # nothing to track (and nothing to recover)
+        return [np.zeros((0, 13)) for _ in range(n_frames)]
+    pairs = []
+    if len(k0) == 0:
+        pairs = [(None, o) for o in k1]
+    else:
+        free = list(range(len(k1)))
+        for cur in k0:
+            match = None
+            if free:
+                ious = three_d_iou(cur[:7], k1[:, :7])     # over all of frame 1, as the reference
+                best = int(np.argmax(ious))
+                if ious[best] > 0:
+                    match = k1[best]
+                    free.remove(best)
+            pairs.append((cur, match))
+        pairs += [(None, k1[j]) for j in free]
+    out = [[] for _ in range(n_frames)]
+    for a, b in pairs:
+        for i, o in enumerate(_fill(a, b, n_frames)):
+            if o is not None:
+                out[i].append(o)
+    out = [np.asarray(o, dtype=np.float64).reshape(-1, 13) for o in out]
+    return [out[0]] + [rec(i, out[i]) for i in range(1, n_frames)]
