@@ -16,6 +16,7 @@ PTS_VELO_XYZI, PTS_CAM_3XN = 0, 1
 EXTRACTOR_VGG_PYR = 0
 EXTRACTOR_SHARED_GPU = 0x100
 EXTRACTOR_BF16 = 0x200
+EXTRACTOR_SPLIT = 0x400
 FC_RELU = 1
 FC_BF16 = 2
 

@@ -17,11 +17,13 @@ class _VggPyr(object):
     def __init__(self, extractor_config=None, ctx=None, shared_gpu=False, conv_dtype='f32'):
         """shared_gpu: other streams keep the GPU busy beside this net (the frame-pair
         pipeline): layers run as single launches (include/dodt_hip.h).
-        conv_dtype: 'f32' (the reference's arithmetic) or 'bf16' (bf16 MFMA, fp32
-        accumulate; DODT_EXTRACTOR_BF16)."""
-        if conv_dtype not in ('f32', 'bf16'):
-            raise ValueError("conv_dtype must be 'f32' or 'bf16'")
+        conv_dtype: 'f32' (fp32 MFMA, the reference's arithmetic), 'f32s' (split mode: hi + lo
+        bf16 pairs on the bf16 MFMA, fp32-grade, DODT_EXTRACTOR_SPLIT) or 'bf16' (bf16 MFMA,
+        fp32 accumulate; DODT_EXTRACTOR_BF16)."""
+        if conv_dtype not in ('f32', 'f32s', 'bf16'):
+            raise ValueError("conv_dtype must be 'f32', 'f32s' or 'bf16'")
         self._bf16 = conv_dtype == 'bf16'
+        self._split = conv_dtype == 'f32s'
         self.config = extractor_config
         self._ctx = ctx
         self._shared_gpu = bool(shared_gpu)
@@ -40,7 +42,8 @@ class _VggPyr(object):
         _lib.check(self._ctx.lib.dodt_extractor_create(
             self._ctx.handle,
             _lib.EXTRACTOR_VGG_PYR | (_lib.EXTRACTOR_SHARED_GPU if self._shared_gpu else 0)
-            | (_lib.EXTRACTOR_BF16 if self._bf16 else 0),
+            | (_lib.EXTRACTOR_BF16 if self._bf16 else 0)
+            | (_lib.EXTRACTOR_SPLIT if self._split else 0),
             h, w, c, self.PAD_TOP,
             batch, C.byref(hnd)), 'dodt_extractor_create')
         self._handle = hnd

@@ -61,13 +61,15 @@ const std::vector<KernelVariant>& variants() {
     static const std::vector<KernelVariant> all = [] {
         std::vector<KernelVariant> a = v;
         for (const KernelVariant& b : dodt::bf16_variants()) a.push_back(b);
+        for (const KernelVariant& b : dodt::split_variants()) a.push_back(b);
         return a;
     }();
     return all;
 }
 
 // smallest padded pixel count wins; ties go to the larger output tile
-int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int batch, int num_cus) {
+int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int parts, int batch,
+                 int num_cus) {
     const auto& vs = variants();
     const bool small = Cin < dodt::kCK;
     int best = -1;
@@ -75,7 +77,7 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int ba
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
         if (v.deconv != deconv || v.small_cin != small || v.tail_only || v.bf16 != bf16 ||
-            Cout % v.BN != 0)
+            v.parts != parts || Cout % v.BN != 0)
             continue;
         static const int max_bn = getenv("DODT_CONV_MAX_BN") ? atoi(getenv("DODT_CONV_MAX_BN")) : 1024;
         if (v.BN > max_bn) continue;
@@ -176,7 +178,8 @@ struct Buffer {
     int H = 0, W = 0, C = 0;
     float* ptr = nullptr;
     bool bf16 = false;   // CB16 bf16 map (2 bytes per element) instead of CB8 / NHWC fp32
-    size_t frame_floats() const { return (size_t)H * W * C / (bf16 ? 2 : 1); }
+    int parts = 1;       // 2: split mode, [hi map of all frames | lo map of all frames]
+    size_t frame_floats() const { return (size_t)H * W * C / (bf16 ? 2 : 1); }   // one part
 };
 
 // one kernel launch of a layer: a variant and the work items it walks
@@ -209,6 +212,7 @@ struct dodt_extractor {
     dodt_ctx* ctx = nullptr;
     int in_h = 0, in_w = 0, in_c = 0, pad_top = 0, batch = 0;
     bool bf16 = false;  // conv path on bf16 MFMA (fp32 accumulate, fp32 BN/ReLU, bf16 maps)
+    int parts = 1;      // 2: split mode (hi + lo bf16 maps and weights, three MFMAs per term)
     int H = 0, W = 0;  // padded input size
     Buffer buf[NBUF];
     std::vector<Layer> layers;
@@ -263,6 +267,9 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.counter_base = ex->d_counters + 64;
     a.items = ln.d_items;
     a.n_items = ln.n_items;
+    a.in_part_stride = (long long)src.frame_floats() * ex->batch;
+    a.out_part_stride = (long long)dst.frame_floats() * ex->batch;
+    a.pool_part_stride = pool_dst >= 0 ? (long long)ex->buf[pool_dst].frame_floats() * ex->batch : 0;
     a.pool_out = pool_dst >= 0 ? ex->buf[pool_dst].ptr : nullptr;
     a.pool_frame_stride = pool_dst >= 0 ? (long long)ex->buf[pool_dst].frame_floats() : 0;
     a.bneck_w = bneck_out ? ex->d_bneck_w : nullptr;
@@ -394,10 +401,11 @@ extern "C" {
 int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c, int pad_top,
                           int batch, dodt_extractor** out) {
     DODT_REQUIRE(ctx && out, "dodt_extractor_create: NULL argument");
-    const bool bf16 = (kind & DODT_EXTRACTOR_BF16) != 0;
+    const bool split = (kind & DODT_EXTRACTOR_SPLIT) != 0;
+    const bool bf16 = (kind & DODT_EXTRACTOR_BF16) != 0 || split;
     // (the bf16 kernels have no quarter-size instantiations: single launches)
     const bool shared_gpu = (kind & DODT_EXTRACTOR_SHARED_GPU) != 0 || bf16;
-    kind &= ~(DODT_EXTRACTOR_SHARED_GPU | DODT_EXTRACTOR_BF16);
+    kind &= ~(DODT_EXTRACTOR_SHARED_GPU | DODT_EXTRACTOR_BF16 | DODT_EXTRACTOR_SPLIT);
     DODT_REQUIRE(kind == DODT_EXTRACTOR_VGG_PYR, "dodt_extractor_create: unknown kind %d", kind);
     DODT_REQUIRE(in_h > 0 && in_w > 0 && in_c >= 2 && in_c % 2 == 0 && pad_top >= 0 && batch >= 1,
                  "dodt_extractor_create: bad sizes (in_c must be even)");
@@ -412,6 +420,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     ex->in_h = in_h; ex->in_w = in_w; ex->in_c = in_c; ex->pad_top = pad_top; ex->batch = batch;
     ex->H = H; ex->W = W;
     ex->bf16 = bf16;
+    ex->parts = split ? 2 : 1;
     auto setb = [&](int id, int h, int w, int c) { ex->buf[id].H = h; ex->buf[id].W = w; ex->buf[id].C = c; };
     setb(X0, H, W, in_c);
     setb(C1A, H, W, 32); setb(CAT1, H, W, 64); setb(P1, H / 2, W / 2, 32);
@@ -420,10 +429,13 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     setb(P3, H / 8, W / 8, 128);
     setb(C4A, H / 8, W / 8, 256); setb(C4B, H / 8, W / 8, 256); setb(C4C, H / 8, W / 8, 256);
     setb(F3, H / 4, W / 4, 64); setb(F2, H / 2, W / 2, 32); setb(F1, H, W, 32);
-    for (int i = 0; i < NBUF; ++i) ex->buf[i].bf16 = bf16 && i != X0 && i != F1;
+    for (int i = 0; i < NBUF; ++i) {
+        ex->buf[i].bf16 = bf16 && i != X0 && i != F1;
+        ex->buf[i].parts = ex->buf[i].bf16 ? ex->parts : 1;
+    }
     for (int i = 0; i < NBUF; ++i) {
         if (i == F1) continue;  // the last layer writes into the caller's buffer
-        const size_t bytes = ex->buf[i].frame_floats() * batch * sizeof(float);
+        const size_t bytes = ex->buf[i].frame_floats() * batch * ex->buf[i].parts * sizeof(float);
         hipError_t e = hipMalloc(&ex->buf[i].ptr, bytes);
         if (e != hipSuccess) {
             dodt::set_error("dodt_extractor_create: hipMalloc(%zu) failed: %s", bytes,
@@ -442,7 +454,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         Layer l;
         l.name = name; l.deconv = deconv; l.H = h; l.W = w; l.Cin = cin; l.Cout = cout;
         l.src = src; l.src_coff = src_coff; l.dst = dst; l.dst_coff = dst_coff;
-        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, batch, ctx->num_cus);
+        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, ex->parts, batch, ctx->num_cus);
         l.real_cin = cin;
         ex->layers.push_back(l);
     };
@@ -574,9 +586,14 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
                 } else if (!w16) {   // [n_tile][chunk][tap][h = c/4][n][s = c%4]
                     blocked[(((((size_t)nt * nchunks + ch) * 9 + tap) * 2 + c / 4) * v.BN + n) * 4 +
                             c % 4] = val;
-                } else {             // [n_tile][chunk16][tap][h = c/8][n][j = c%8] bf16
-                    blocked16[(((((size_t)nt * nchunks + ch) * 9 + tap) * 2 + c / 8) * v.BN + n) * 8 +
-                              c % 8] = dodt::float_to_bf16(val);
+                } else {   // [n_tile][chunk16][part][tap][h = c/8][n][j = c%8] bf16
+                    const uint16_t hi = dodt::float_to_bf16(val);
+                    const size_t base = ((size_t)nt * nchunks + ch) * v.parts;
+                    const size_t in = ((size_t)(tap * 2 + c / 8) * v.BN + n) * 8 + c % 8;
+                    blocked16[(base + 0) * 9 * 2 * v.BN * 8 + in] = hi;
+                    if (v.parts == 2)    // lo = bf16(w - hi): w = hi + lo to 16 mantissa bits
+                        blocked16[(base + 1) * 9 * 2 * v.BN * 8 + in] =
+                            dodt::float_to_bf16(val - dodt::bf16_to_float(hi));
                 }
             }
     if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, blocked.size() * sizeof(float)));
@@ -707,6 +724,17 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
                     o[px * l.Cout + pl * pc + k] =
                         b.bf16 ? dodt::bf16_to_float(tmp16[(pl * plane + px * 8) * 2 + k])
                                : tmp[pl * plane + px * 8 + k];
+        if (b.parts == 2) {   // split mode: add the lo map
+            DODT_HIP_CHECK(hipMemcpy(tmp.data(),
+                                     b.ptr + (size_t)(ex->batch + f) * b.frame_floats() +
+                                         (size_t)(l.dst_coff / pc) * plane,
+                                     tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int pl = 0; pl < planes; ++pl)
+                for (size_t px = 0; px < (size_t)oh * ow; ++px)
+                    for (int k = 0; k < pc; ++k)
+                        o[px * l.Cout + pl * pc + k] +=
+                            dodt::bf16_to_float(tmp16[(pl * plane + px * 8) * 2 + k]);
+        }
     }
     return DODT_OK;
 }

@@ -77,6 +77,9 @@ struct ConvArgs {
     float* bneck_out;              // (frames, H - out_y0, W)
     float bneck_scale, bneck_shift;
     long long bneck_frame_stride;  // floats between frames of bneck_out
+    // split mode (PARTS = 2): a map is a hi bf16 map followed, part_stride floats further, by
+    // the lo map (value = hi + lo); strides of the input, output and pooled maps
+    long long in_part_stride, out_part_stride, pool_part_stride;
     int debug;     // ablation switches for tools/ (0 in production): 1 = no epilogue
                    // stores, 2 = no global loads in the K loop, 4 = no MFMAs
 };
@@ -84,7 +87,10 @@ struct ConvArgs {
 constexpr int kCK = 8;          // input channels per K chunk = one CB8 plane
 constexpr int kPixStride = 12;  // floats per LDS pixel: 8 channels + 4 pad (48 B)
 
-template <int TW, int MTB, int WM, int WN, int BN, bool DECONV>
+// PARTS = 2: the "split" mode.  fp32 values are carried as hi + lo bf16 (16 mantissa bits),
+// every LDS image exists twice (hi | lo) and a product is three bf16 MFMAs
+// (w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulate): fp32-grade results from the bf16 pipe.
+template <int TW, int MTB, int WM, int WN, int BN, bool DECONV, int PARTS = 1>
 struct ConvCfg {
     static constexpr int kRowsPerMT = 32 / TW;
     static constexpr int TH = MTB * kRowsPerMT;
@@ -92,11 +98,13 @@ struct ConvCfg {
     static constexpr int PW = DECONV ? TW + 1 : TW + 2;
     static constexpr int MT = MTB / WM;
     static constexpr int NT = BN / 32 / WN;
-    static constexpr int kPatchFloats = PH * PW * kPixStride;
-    static constexpr int kWFloats = 9 * kCK * BN;
+    static constexpr int kPatchFloats1 = PH * PW * kPixStride;   // one part
+    static constexpr int kWFloats1 = 9 * kCK * BN;
+    static constexpr int kPatchFloats = PARTS * kPatchFloats1;
+    static constexpr int kWFloats = PARTS * kWFloats1;
     static constexpr int kBufFloats = kPatchFloats + kWFloats;  // one chunk: patch | weights
     static constexpr int kLdsBytes = 2 * kBufFloats * 4 + 16;    // double buffered + control
-    static constexpr int kPatchItems = PH * PW * 2;       // float4 per chunk
+    static constexpr int kPatchItems = PARTS * PH * PW * 2;   // float4 per chunk
     static constexpr int kWItems = kWFloats / 4;          // float4 per chunk
     static constexpr int NP = (kPatchItems + 255) / 256;  // per-thread prefetch regs
     static constexpr int NW = (kWItems + 255) / 256;
@@ -105,7 +113,9 @@ struct ConvCfg {
     static constexpr int kAccRegs = (DECONV ? 4 * NT : MT * NT) * 16;
     // persistent workgroups hide their own prologue/epilogue, so two per CU suffice:
     // give the register allocator the full 256-register budget of 2 waves per SIMD
-    static constexpr int kMinWaves = 2;
+    // (split mode: the doubled LDS images leave room for one workgroup per CU anyway, and
+    // the doubled fragments and staging registers need more than 256 registers)
+    static constexpr int kMinWaves = PARTS == 2 ? 1 : 2;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MTB % WM == 0 && (BN / 32) % WN == 0, "tile split");
     static_assert(!DECONV || MT == 1, "deconv: one 32-pixel tile per wave (x 4 parity classes)");
@@ -129,6 +139,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(f32x4 w, f32x4 x, f32x16 c) {
 __device__ __forceinline__ float pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(float, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
+// the float value of half `which` (0 = low 16 bits) of a packed bf16 pair
+__device__ __forceinline__ float bf16_value(float packed, int which) {
+    const unsigned u = __builtin_bit_cast(unsigned, packed);
+    return __builtin_bit_cast(float, which ? (u & 0xffff0000u) : (u << 16));
+}
 // Channel of accumulator register group g (4 consecutive channels) of lane half lh inside a
 // 32-channel tile.  fp32 kernels: MFMA row order, 8g + 4lh.  bf16 kernels (PERM): the host
 // permutes the weight rows so that a lane's 16 channels are two runs of 8 consecutive ones
@@ -142,13 +157,15 @@ __device__ __forceinline__ int group_channel(int g, int lh) {
 // Lane (li = pixel, lh): register group g = r>>2 holds channels c0 + 8g + 4lh + (r&3).
 // KEEP: the activated values replace the accumulators (for the fused pool).
 // PERM: channel order of bf16 kernels; OUT16: store bf16 into a CB16 map (needs PERM).
-template <bool KEEP = false, bool PERM = false, bool OUT16 = false>
+// SPLIT (with OUT16): write hi = bf16(v) and lo = bf16(v - hi) maps.
+template <bool KEEP = false, bool PERM = false, bool OUT16 = false, bool SPLIT = false>
 __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16& acc,
                                            int c0, int lh, int y, int x, int out_w,
                                            long long plane_stride, bool ok, int frame = 0) {
     static_assert(!OUT16 || PERM, "bf16 output needs the permuted channel order");
     float dot = 0.0f;   // this lane's 16 channels of the fused 1x1 bottleneck
     f32x2 half = {0.f, 0.f};   // OUT16: the even group's four channels, packed
+    f32x2 half_lo = {0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c = c0 + group_channel<PERM>(g, lh);
@@ -173,13 +190,25 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16
         }
         if constexpr (OUT16) {
             // groups (0,1) and (2,3) are 8 consecutive channels each: one 16-byte store
+            f32x2 hi = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            f32x2 lo = {0.f, 0.f};
+            if constexpr (SPLIT) {
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)   // residual against the rounded hi part
+                    r[k] = v[k] - bf16_value(hi[k >> 1], k & 1);
+                lo = f32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
+            }
             if (!(g & 1)) {
-                half = f32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                half = hi;
+                half_lo = lo;
             } else if (ok) {
                 float* dst = out + (size_t)((a.out_coff + c) >> 4) * plane_stride +
                              ((size_t)y * out_w + x) * 8 + 4 * lh;
-                *reinterpret_cast<f32x4*>(dst) =
-                    f32x4{half[0], half[1], pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                *reinterpret_cast<f32x4*>(dst) = f32x4{half[0], half[1], hi[0], hi[1]};
+                if constexpr (SPLIT)
+                    *reinterpret_cast<f32x4*>(dst + a.out_part_stride) =
+                        f32x4{half_lo[0], half_lo[1], lo[0], lo[1]};
             }
         } else if (ok) {
             float* dst;
@@ -204,7 +233,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out, f32x16
 // 2x2/2 max pool of one activated 32(channel) x 32(pixel) tile: the horizontal neighbour
 // is lane ^ 1, the vertical one lane ^ TW (two or more rows per 32-pixel tile) or the same
 // lane of the next row's tile (`below`, TW == 32).  Lanes at even (y, x) store.
-template <int TW, bool PERM = false, bool OUT16 = false>
+template <int TW, bool PERM = false, bool OUT16 = false, bool SPLIT = false>
 __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, const f32x16& below,
                                           int c0, int lh, int y, int x, int frame, bool ok) {
     const int OW = a.W >> 1;
@@ -212,7 +241,7 @@ __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, co
     float* base = a.pool_out + (size_t)frame * a.pool_frame_stride +
                   ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
     const bool writer = ok && !(y & 1) && !(x & 1);
-    f32x2 half = {0.f, 0.f};
+    f32x2 half = {0.f, 0.f}, half_lo = {0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 m;
@@ -225,11 +254,24 @@ __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, co
         }
         const int c = c0 + group_channel<PERM>(g, lh);
         if constexpr (OUT16) {
-            if (!(g & 1))
-                half = f32x2{pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3])};
-            else if (writer)
-                *reinterpret_cast<f32x4*>(base + (size_t)(c >> 4) * plane) =
-                    f32x4{half[0], half[1], pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3])};
+            f32x2 hi = {pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3])};
+            f32x2 lo = {0.f, 0.f};
+            if constexpr (SPLIT) {
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = m[k] - bf16_value(hi[k >> 1], k & 1);
+                lo = f32x2{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
+            }
+            if (!(g & 1)) {
+                half = hi;
+                half_lo = lo;
+            } else if (writer) {
+                float* dst = base + (size_t)(c >> 4) * plane;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{half[0], half[1], hi[0], hi[1]};
+                if constexpr (SPLIT)
+                    *reinterpret_cast<f32x4*>(dst + a.pool_part_stride) =
+                        f32x4{half_lo[0], half_lo[1], lo[0], lo[1]};
+            }
         } else if (writer) {
             *reinterpret_cast<f32x4*>(base + (size_t)(c >> 3) * plane) = m;
         }
@@ -238,11 +280,13 @@ __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, co
 
 // BF16: activations are CB16 bf16 maps (32 bytes per pixel and plane, like CB8 fp32: all
 // staging below is byte-identical), a K chunk is 16 channels and one MFMA per tap and tile.
-template <int TW, int MTB, int WM, int WN, int BN, bool DECONV, bool BF16 = false>
+template <int TW, int MTB, int WM, int WN, int BN, bool DECONV, bool BF16 = false, int PARTS = 1>
 __global__ void
-__launch_bounds__(256, (ConvCfg<TW, MTB, WM, WN, BN, DECONV>::kMinWaves))
+__launch_bounds__(256, (ConvCfg<TW, MTB, WM, WN, BN, DECONV, PARTS>::kMinWaves))
 conv3x3_mfma_kernel(const ConvArgs a) {
-    using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
+    static_assert(PARTS == 1 || BF16, "the split mode runs on the bf16 MFMA");
+    constexpr bool SPLIT = PARTS == 2;
+    using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV, PARTS>;
     constexpr int PW = Cfg::PW;
     constexpr int MT = Cfg::MT, NT = Cfg::NT, NP = Cfg::NP, NW = Cfg::NW;
     constexpr int NACC = DECONV ? 4 * NT : MT * NT;
@@ -287,11 +331,17 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int t = tid + k * 256;
-            const int g = t & 1, p = t >> 1;
+            const int g = t & 1;
+            int p = t >> 1;
+            int part_off = 0;                       // split mode: the second half is the lo map
+            if (SPLIT && p >= Cfg::PH * PW) {
+                p -= Cfg::PH * PW;
+                part_off = (int)a.in_part_stride;
+            }
             const int py = p / PW, px = p - py * PW;
             const int gy = it.ty0 - 1 + py, gx = it.tx0 - 1 + px;
             const bool ok = t < Cfg::kPatchItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            p_glb[k] = ok ? (gy * a.W + gx) * 8 + g * 4 : 0;
+            p_glb[k] = ok ? part_off + (gy * a.W + gx) * 8 + g * 4 : 0;
             ok_issue |= (ok ? 1u : 0u) << k;
         }
         in_item = a.in + (size_t)it.frame * a.in_frame_stride +
@@ -417,24 +467,42 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             DODT_FOR_SLOTS(DODT_ABL)
         } else if constexpr (!DECONV) {
             f32x4 xf[2][MT], wf[2][NT];
+            f32x4 xl[2][SPLIT ? MT : 1], wl[2][SPLIT ? NT : 1];   // lo parts (split mode)
+            constexpr int kXlo = Cfg::kPatchFloats1, kWlo = Cfg::kWFloats1;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
                 xf[0][mt] = *reinterpret_cast<const f32x4*>(
                     bP + x_base + (mt * Cfg::kRowsPerMT * PW) * PS);
+                if constexpr (SPLIT)
+                    xl[0][mt] = *reinterpret_cast<const f32x4*>(
+                        bP + kXlo + x_base + (mt * Cfg::kRowsPerMT * PW) * PS);
+            }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt) {
                 wf[0][nt] = *reinterpret_cast<const f32x4*>(bW + w_base + nt * 128);
+                if constexpr (SPLIT)
+                    wl[0][nt] = *reinterpret_cast<const f32x4*>(bW + kWlo + w_base + nt * 128);
+            }
 #define DODT_TAP(TAP)                                                                         \
             {                                                                                 \
                 constexpr int cb = (TAP) & 1, nb = cb ^ 1;                                    \
                 if constexpr ((TAP) + 1 < 9) {                                                \
                     constexpr int ky = ((TAP) + 1) / 3, kx = ((TAP) + 1) % 3;                 \
-                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                       \
                         xf[nb][mt] = *reinterpret_cast<const f32x4*>(                         \
                             bP + x_base + ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);      \
-                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                        if constexpr (SPLIT)                                                  \
+                            xl[nb][mt] = *reinterpret_cast<const f32x4*>(                     \
+                                bP + kXlo + x_base +                                          \
+                                ((mt * Cfg::kRowsPerMT + ky) * PW + kx) * PS);                \
+                    }                                                                         \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                       \
                         wf[nb][nt] = *reinterpret_cast<const f32x4*>(                         \
                             bW + w_base + ((TAP) + 1) * 2 * BN * 4 + nt * 128);               \
+                        if constexpr (SPLIT)                                                  \
+                            wl[nb][nt] = *reinterpret_cast<const f32x4*>(                     \
+                                bW + kWlo + w_base + ((TAP) + 1) * 2 * BN * 4 + nt * 128);    \
+                    }                                                                         \
                 }                                                                             \
                 /* the next tap's LDS reads stay ABOVE this tap's MFMAs (hipcc would */       \
                 /* otherwise sink them below to save registers and expose their latency) */   \
@@ -445,6 +513,18 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                             acc[mt * NT + nt] =                                               \
                                 mfma_bf16(wf[cb][nt], xf[cb][mt], acc[mt * NT + nt]);         \
                     DODT_STAGE_TAP(TAP)                                                       \
+                    if constexpr (SPLIT) {   /* the two cross terms, small ones last */        \
+                        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
+                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                 \
+                                acc[mt * NT + nt] = mfma_bf16(                                \
+                                    wf[cb][nt], xl[cb][mt < (SPLIT ? MT : 1) ? mt : 0],       \
+                                    acc[mt * NT + nt]);                                       \
+                        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
+                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                 \
+                                acc[mt * NT + nt] = mfma_bf16(                                \
+                                    wl[cb][nt < (SPLIT ? NT : 1) ? nt : 0], xf[cb][mt],       \
+                                    acc[mt * NT + nt]);                                       \
+                    }                                                                         \
                 } else {                                                                      \
                     _Pragma("unroll") for (int s = 0; s < 2; ++s)                             \
                         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
@@ -474,25 +554,39 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         } else {
             // patch origin is (ty0-1, tx0-1): in[i][j] sits at patch (r+1, c+1)
             const float* pa = bP + x_base;
-            f32x4 af[4];
+            f32x4 af[4], al[SPLIT ? 4 : 1];
+            constexpr int kXlo = Cfg::kPatchFloats1, kWlo = Cfg::kWFloats1;
             af[0] = *reinterpret_cast<const f32x4*>(pa + (PW + 1) * PS);  // in[i][j]
             af[1] = *reinterpret_cast<const f32x4*>(pa + 1 * PS);         // in[i-1][j]
             af[2] = *reinterpret_cast<const f32x4*>(pa + PW * PS);        // in[i][j-1]
             af[3] = *reinterpret_cast<const f32x4*>(pa);                  // in[i-1][j-1]
+            if constexpr (SPLIT) {
+                al[0] = *reinterpret_cast<const f32x4*>(pa + kXlo + (PW + 1) * PS);
+                al[1] = *reinterpret_cast<const f32x4*>(pa + kXlo + 1 * PS);
+                al[2] = *reinterpret_cast<const f32x4*>(pa + kXlo + PW * PS);
+                al[3] = *reinterpret_cast<const f32x4*>(pa + kXlo);
+            }
             // taps ky*3+kx; out[2i+ky-2*di][2j+kx-2*dj] += in[i-di][j-dj] * w[ky][kx]: every
             // tap feeds one output-parity class from one of the four input pixels.  Order:
             // classes alternate so that consecutive taps use different accumulators.
-            f32x4 bw[2][NT];
+            f32x4 bw[2][NT], bl[2][SPLIT ? NT : 1];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt) {
                 bw[0][nt] = *reinterpret_cast<const f32x4*>(bW + w_base + nt * 128);   // tap 0
+                if constexpr (SPLIT)
+                    bl[0][nt] = *reinterpret_cast<const f32x4*>(bW + kWlo + w_base + nt * 128);
+            }
 #define DODT_DTAP(I, TAP, CLS, AF, NEXT_TAP)                                                  \
             {                                                                                 \
                 constexpr int cb = (I) & 1, nb = cb ^ 1;                                      \
                 if constexpr ((NEXT_TAP) >= 0) {                                              \
-                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                       \
                         bw[nb][nt] = *reinterpret_cast<const f32x4*>(                         \
                             bW + w_base + (NEXT_TAP) * 2 * BN * 4 + nt * 128);                \
+                        if constexpr (SPLIT)                                                  \
+                            bl[nb][nt] = *reinterpret_cast<const f32x4*>(                     \
+                                bW + kWlo + w_base + (NEXT_TAP) * 2 * BN * 4 + nt * 128);     \
+                    }                                                                         \
                 }                                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                            \
                 if constexpr (BF16) {                                                         \
@@ -500,6 +594,14 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                         acc[(CLS) * NT + nt] =                                                \
                             mfma_bf16(bw[cb][nt], af[AF], acc[(CLS) * NT + nt]);              \
                     DODT_STAGE_TAP(I)                                                         \
+                    if constexpr (SPLIT) {                                                    \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
+                            acc[(CLS) * NT + nt] = mfma_bf16(                                 \
+                                bw[cb][nt], al[SPLIT ? (AF) : 0], acc[(CLS) * NT + nt]);      \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
+                            acc[(CLS) * NT + nt] = mfma_bf16(                                 \
+                                bl[cb][SPLIT ? nt : 0], af[AF], acc[(CLS) * NT + nt]);        \
+                    }                                                                         \
                 } else {                                                                      \
                     _Pragma("unroll") for (int s = 0; s < 2; ++s)                             \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                     \
@@ -550,11 +652,13 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                         const int c0 = cur.ntile * BN + (wn * NT + nt) * 32;
                         // bf16 kernels store bf16 CB16 maps, except the net's last layer (NHWC fp32)
                         if (pool)
-                            store_tile<true, BF16, BF16>(a, out, acc[mt * NT + nt], c0, lh,
-                                                         y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                            store_tile<true, BF16, BF16, SPLIT>(a, out, acc[mt * NT + nt], c0, lh,
+                                                                y - a.out_y0, x, a.W, plane, ok,
+                                                                cur.frame);
                         else if (BF16 && !a.out_nhwc)
-                            store_tile<false, BF16, BF16>(a, out, acc[mt * NT + nt], c0, lh,
-                                                          y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                            store_tile<false, BF16, BF16, SPLIT>(a, out, acc[mt * NT + nt], c0, lh,
+                                                                 y - a.out_y0, x, a.W, plane, ok,
+                                                                 cur.frame);
                         else
                             store_tile<false, BF16, false>(a, out, acc[mt * NT + nt], c0, lh,
                                                            y - a.out_y0, x, a.W, plane, ok, cur.frame);
@@ -569,7 +673,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                             const bool ok = st && y < a.H && x < a.W;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                pool_tile<TW, BF16, BF16>(a, acc[mt * NT + nt],
+                                pool_tile<TW, BF16, BF16, SPLIT>(a, acc[mt * NT + nt],
                                               acc[(Cfg::kRowsPerMT >= 2 ? mt : mt + 1) * NT + nt],
                                               cur.ntile * BN + (wn * NT + nt) * 32, lh, y, x,
                                               cur.frame, ok);
@@ -585,7 +689,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
                 for (int cls = 0; cls < 4; ++cls)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        store_tile<false, BF16, BF16>(a, out, acc[cls * NT + nt],
+                        store_tile<false, BF16, BF16, SPLIT>(a, out, acc[cls * NT + nt],
                                                       cur.ntile * BN + (wn * NT + nt) * 32, lh,
                                                       2 * y + (cls >> 1), 2 * x + (cls & 1),
                                                       2 * a.W, plane, ok);
@@ -647,7 +751,7 @@ struct SmallCfg {
 
 // OUT16: the output is a CB16 bf16 map (the arithmetic stays fp32; the host permutes the
 // weights' output channels like for the bf16 kernels).
-template <int TW, int MTB, int CK, bool OUT16 = false>
+template <int TW, int MTB, int CK, bool OUT16 = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
 conv3x3_small_cin_kernel(const ConvArgs a) {
     using Cfg = SmallCfg<TW, MTB, CK>;
@@ -721,7 +825,7 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
         const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
         const int x = tx0 + li % TW;
-        store_tile<false, OUT16, OUT16>(a, out, acc[mt], 0, lh, y, x, a.W, plane,
+        store_tile<false, OUT16, OUT16, SPLIT>(a, out, acc[mt], 0, lh, y, x, a.W, plane,
                                         y < a.H && x < a.W);
     }
 }

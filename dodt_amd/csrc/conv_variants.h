@@ -16,6 +16,7 @@ struct KernelVariant {
     hipError_t (*prepare)();
     bool tail_only = false;  // quarter-size tiles: never a layer's main variant
     bool bf16 = false;       // CB16 bf16 activations (first-layer kernels: bf16 OUTPUT)
+    int parts = 1;           // 2: split mode, every map is a hi + lo pair of bf16 maps
 };
 
 inline KernelVariant tail_only(KernelVariant v) {
@@ -23,16 +24,17 @@ inline KernelVariant tail_only(KernelVariant v) {
     return v;
 }
 
-template <int TW, int MTB, int WM, int WN, int BN, bool DECONV, bool BF16 = false>
+template <int TW, int MTB, int WM, int WN, int BN, bool DECONV, bool BF16 = false, int PARTS = 1>
 struct Inst {
-    using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV>;
+    using Cfg = ConvCfg<TW, MTB, WM, WN, BN, DECONV, PARTS>;
+    static_assert(Cfg::kLdsBytes <= 160 * 1024, "variant does not fit the LDS");
     static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV, BF16>), grid,
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV, BF16, PARTS>), grid,
                            dim3(256), Cfg::kLdsBytes, s, a);
     }
     static hipError_t prepare() {
         return hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV, BF16>),
+            reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TW, MTB, WM, WN, BN, DECONV, BF16, PARTS>),
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
     }
     static KernelVariant variant() {
@@ -42,31 +44,34 @@ struct Inst {
         KernelVariant v{TW, MTB, WM, WN, BN, BF16 ? 16 : kCK, DECONV, false, Cfg::TH,
                         Cfg::kLdsBytes, per_cu, &launch, &prepare};
         v.bf16 = BF16;
+        v.parts = PARTS;
         return v;
     }
 };
 
-template <int TW, int MTB, int CK, bool OUT16 = false>
+template <int TW, int MTB, int CK, bool OUT16 = false, bool SPLIT = false>
 struct InstSmall {
     using Cfg = SmallCfg<TW, MTB, CK>;
     static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL((conv3x3_small_cin_kernel<TW, MTB, CK, OUT16>), grid, dim3(256),
+        hipLaunchKernelGGL((conv3x3_small_cin_kernel<TW, MTB, CK, OUT16, SPLIT>), grid, dim3(256),
                            Cfg::kLdsBytes, s, a);
     }
     static hipError_t prepare() {
         return hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv3x3_small_cin_kernel<TW, MTB, CK, OUT16>),
+            reinterpret_cast<const void*>(&conv3x3_small_cin_kernel<TW, MTB, CK, OUT16, SPLIT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
     }
     static KernelVariant variant() {
         KernelVariant v{TW, MTB, 4, 1, 32, CK, false, true, Cfg::TH, Cfg::kLdsBytes, 4, &launch,
                         &prepare};
         v.bf16 = OUT16;
+        v.parts = SPLIT ? 2 : 1;
         return v;
     }
 };
 
-// conv_bf16.hip
+// conv_bf16.hip, conv_split.hip
 std::vector<KernelVariant> bf16_variants();
+std::vector<KernelVariant> split_variants();
 
 }  // namespace dodt

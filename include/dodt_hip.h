@@ -181,6 +181,12 @@ typedef struct dodt_extractor dodt_extractor;
  * reference computes in fp32: with this flag conv outputs agree with an fp32
  * run to ~1e-2 of their scale, not 1e-4 (tests/test_gpu_conv_bf16.py states the bars). */
 #define DODT_EXTRACTOR_BF16 0x200
+/* OR into `kind`: fp32-grade convs on the bf16 MFMA ("split" mode).  Every stored activation
+ * and every weight is a pair hi + lo of bf16 values (16 mantissa bits), a product is
+ * w_hi x_hi + w_hi x_lo + w_lo x_hi in three bf16 MFMAs with fp32 accumulation: relative
+ * error ~2^-16 per product instead of bf16's 2^-8, within the 1e-4 bar of the fp32 tests
+ * (tests/test_gpu_conv_split.py runs them at the fp32 tolerances). */
+#define DODT_EXTRACTOR_SPLIT 0x400
 /* in_c: channels of the input tensor as stored (6 for BEV; 4 for the padded
  * image); pad_top: zero rows added on top (4 for BEV 700->704, 0 for images);
  * batch: frames processed per forward call (2 = both frames of a pair). */
