@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--heads', choices=('computed', 'injected'), default='computed',
                     help='dense heads + correlation branch on the device (the whole path), '
                          'or their outputs injected from HBM')
-    ap.add_argument('--conv-dtype', choices=('f32', 'bf16'), default='f32',
+    ap.add_argument('--conv-dtype', choices=('f32', 'f32s', 'bf16'), default='f32',
                     help="arithmetic of the conv stacks: 'f32' = the reference's (fp32 MFMA), "
                          "'bf16' = BASELINE configs[2]'s bf16 conv path (bf16 MFMA, fp32 accumulate)")
     ap.add_argument('--head-dtype', choices=('f32', 'bf16'), default='f32',
@@ -259,18 +259,22 @@ def main():
                     'steps': k, 'ms_per_step': round(a['elapsed'] / k * 1e3, 4),
                     'conv_stacks_tflops': round(a['flops'] / (a['conv_ms'] * 1e-3) / 1e12, 2),
                     'conv_stacks_ms': round(a['conv_ms'], 4)}
-        other = 'bf16' if args.conv_dtype == 'f32' else 'f32'
-        alt = {'note': "bf16 conv = BASELINE.json configs[2]'s bf16 conv path (bf16 MFMA, fp32 "
-                       'accumulate, bf16 maps between layers; bars in tests/test_gpu_conv_bf16.py); '
-                       "bf16 heads = the same for the FC layers; f32 = the reference's arithmetic",
-               'runs': [short(other, 'f32')] + ([short('bf16', 'bf16')] if computed else [])}
+        alt = {'note': "f32s = split mode: hi + lo bf16 pairs, three bf16 MFMAs per product term, "
+                       'fp32 accumulate -- passes the fp32 layer tests at 1e-4 '
+                       '(tests/test_gpu_conv_split.py); bf16 conv = BASELINE.json configs[2]\'s '
+                       'bf16 conv path (bars in tests/test_gpu_conv_bf16.py); bf16 heads = the '
+                       "same for the FC layers; f32 = the reference's arithmetic on the fp32 MFMA",
+               'runs': [short(c, h) for c, h in (('f32', 'f32'), ('f32s', 'f32'), ('bf16', 'f32'),
+                                                  ('bf16', 'bf16'))
+                        if (c, h) != (args.conv_dtype, args.head_dtype) and (computed or h == 'f32')]}
     flops = m['flops']
     achieved = flops / (conv_ms * 1e-3) / 1e12
     # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
     # figure comes from the rocprofv3 --pmc passes over this same command (profiles/)
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, 'profiles', 'r1_conv_traffic.json' if args.conv_dtype == 'f32'
-                      else 'r1bf16_conv_traffic.json')
+    tj = os.path.join(ROOT, 'profiles', {'f32': 'r1_conv_traffic.json',
+                                         'f32s': 'r1f32s_conv_traffic.json',
+                                         'bf16': 'r1bf16_conv_traffic.json'}[args.conv_dtype])
     if os.path.exists(tj):
         t = json.load(open(tj))
         traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
@@ -289,6 +293,12 @@ def main():
         # MFMA-bound at fp32
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=157.3, unit='TFLOP/s',
                         frac=round(achieved / 157.3, 4), **common)
+    elif args.conv_dtype == 'f32s':
+        # split mode: three bf16 MFMAs per product term -> 3x the algorithmic FLOPs on the
+        # bf16 pipe (2.5 PFLOP/s dense); the fp32-equivalent rate is given beside it
+        roofline = dict(bound='mfma', achieved=round(3 * achieved, 2), peak=2500.0, unit='TFLOP/s',
+                        frac=round(3 * achieved / 2500.0, 4), executed_flops='3 x algorithmic',
+                        fp32_equivalent_tflops=round(achieved, 2), **common)
     else:
         # bf16 MFMA (2.5 PFLOP/s) makes the stacks 16x cheaper in matrix time than in fp32:
         # they are bound by moving the maps (HBM ~8 TB/s), which is what is priced here;

@@ -122,7 +122,8 @@ def test_fully_connected_strides_and_device_row_count(ctx):
     fc.close()
 
 
-@pytest.mark.parametrize('conv_dtype,head_dtype', [('f32', 'f32'), ('bf16', 'bf16')])
+@pytest.mark.parametrize('conv_dtype,head_dtype', [('f32', 'f32'), ('f32s', 'f32'),
+                                                   ('bf16', 'bf16')])
 def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head_dtype):
     """Heads computed on the device.  Every dense stage is checked against the oracle on the
     inputs the device produced for it; the index stages downstream are then checked exactly,
@@ -182,7 +183,8 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
         assert np.array_equal(b['top_idx'].download()[:n_top], want['top_idx'])
         n_det = int(b['det_count'].download()[0])
         assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
-        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-5, atol=1e-4)
+        # box regressions: the north_star's 1e-4 (the decode chain has atan2 / sincos in it)
+        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-4, atol=1e-4)
     assert pipe.head_flops_per_step() > 5e10
     with pytest.raises(ValueError):
         pipe.run([], [], [], heads=[{}])
