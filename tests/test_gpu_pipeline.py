@@ -31,8 +31,13 @@ def _run(ctx, pipe, seq, frames, n_points=120000):
     return pts, imgs, heads, list(pipe.last_anchor_counts)
 
 
-def test_frame_pair_matches_oracle(setup):
+@pytest.mark.parametrize('conv_dtype', ['f32', 'f32s'])
+def test_frame_pair_matches_oracle(setup, conv_dtype):
+    """'f32s' (split mode on the bf16 MFMA) is held to the same bars as the fp32 MFMA path."""
     ctx, pipe = setup
+    if conv_dtype != 'f32':
+        pipe = FramePairPipeline(ctx, C, rpn_nms_size=1024, conv_dtype=conv_dtype,
+                                 reuse_streams_of=pipe)
     pts, imgs, heads, counts = _run(ctx, pipe, seq=0, frames=(0, 2))    # tau = 2
     recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
     rcnt = pipe.d_rec_counts.download().reshape(-1)
