@@ -44,12 +44,18 @@ if trace:
     tr = [r for r in csv.DictReader(open(trace)) if 'conv3x3' in r['Kernel_Name']]
     tr.sort(key=lambda r: int(r['Start_Timestamp']))
     reps = 10
-    tail = tr[-reps * 32:]
-    if len(tail) == reps * 32:
-        d = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in tail)
-        lines += ['', "bench.py's roofline section (last %d forwards of each net, run alone): %d conv "
+    # bench.py ends with `reps` forwards of each net alone, then `reps` forwards side by side
+    alone = tr[-2 * reps * 32:-reps * 32]
+    both = tr[-reps * 32:]
+    if len(alone) == reps * 32:
+        d = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in alone)
+        lines += ['', "bench.py's roofline section (%d forwards of each net, run alone): %d conv "
                   'launches, average launch %.1f us, %.3f ms per step (32 launches)' % (
-                      reps, len(tail), d / 1e3 / len(tail), d / 1e6 / reps)]
+                      reps, len(alone), d / 1e3 / len(alone), d / 1e6 / reps)]
+        t0 = min(int(r['Start_Timestamp']) for r in both)
+        t1 = max(int(r['End_Timestamp']) for r in both)
+        lines += ["side-by-side section (%d steps, both nets concurrently): %.3f ms per step" % (
+            reps, (t1 - t0) / 1e6 / reps)]
 
 
 def counters(path):
