@@ -200,13 +200,21 @@ def main():
             step(i)
         drain()
         barrier()
+        # one HIP event per step on the main stream (torch's current stream = ctx's stream):
+        # event i fires when step i's convs and step i-1's tail are done, so the deltas show
+        # a slow fill / drain step or a clock ramp that the single wall-clock window hides
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 2)]
         t0 = time.perf_counter()
+        evs[0].record()
         for i in range(steps):
             step(i)
+            evs[i + 1].record()
         host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3   # host side of a step
         drain()
+        evs[steps + 1].record()
         barrier()
         elapsed = time.perf_counter() - t0
+        step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps + 1)]
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,6 +245,7 @@ def main():
             ctx.wait_for(pipe.img_ctx)
         both_ms = ctx.timer_stop() / reps
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
+                   step_ms=step_ms,
                    both_ms=both_ms,
                    flops=pipe.flops_per_step(), head_gflop=pipe.head_flops_per_step() / 1e9,
                    conv_bytes=pipe.conv_bytes_per_step(),
@@ -315,7 +324,15 @@ def main():
             'value': round(world * args.steps * pps / elapsed, 3),
             'unit': 'frame-pairs/s', 'n_gpus': n_gpus, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4),
-            'host_enqueue_ms_per_step': round(host_enqueue_ms, 3), 'higher_is_better': True,
+            'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
+            # HIP-event time between consecutive steps' completion on the main stream (the
+            # last entry is the drain: the final step's tail with no convs beside it)
+            'step_ms': {'min': round(min(m['step_ms'][:-1]), 3),
+                        'median': round(float(np.median(m['step_ms'][:-1])), 3),
+                        'max': round(max(m['step_ms'][:-1]), 3),
+                        'drain': round(m['step_ms'][-1], 3),
+                        'all': [round(v, 2) for v in m['step_ms']]},
+            'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_dtype, 'data': 'synthetic',
             'head_dtype': args.head_dtype,
             'config': {'workload': 'DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '

@@ -107,7 +107,8 @@ SIGNATURES = {
     'dodt_softmax_fg': (_i, [_vp, _pf, _i, _pi32, _pf]),
     'dodt_gather_rows': (_i, [_vp, _pf, _i, _pi32, _i, _pi32, _pf]),
     'dodt_max_fg_logit': (_i, [_vp, _pf, _i, _i, _pi32, _pf]),
-    'dodt_pack_detections': (_i, [_vp, _pf, _pf, _pf, _pi32, _pi32, _i, _f, _pf, _pi32]),
+    'dodt_pack_detections': (_i, [_vp, _pf, _pf, _pf, _pf, _pi32, _pi32, _i, _f, _pf, _pi32]),
+    'dodt_angle_vector_to_orientation': (_i, [_vp, _pf, _i, _pi32, _pf]),
     'dodt_box_4c_decode': (_i, [_vp, _pf, _pf, _i, _pi32, C.POINTER(_f),
                                 C.POINTER(_f), _pf, _pf, _pf]),
 }

@@ -42,6 +42,9 @@ _COMMON = dict(
     avod_nms_iou_thresh=_f32(0.01),
     rpn_train_nms_size=1024,
     rpn_test_nms_size=300,
+    # avod_box_representation (both configs, e.g. ...dt_5_tracking.config:29): box_4c offsets
+    # plus a regressed angle vector that fixes the heading (dt_evaluator.py:1166-1212)
+    box_representation='box_4ca',
 )
 
 PYRAMID_DODT = dict(_COMMON,

@@ -8,11 +8,14 @@ from dodt_amd import ops
 
 
 class EarlyFusionFcLayers(object):
-    """mean of the input crops -> flatten -> fc6.. (ReLU) -> linear output layers.
-    `outputs` names the output layers in params, e.g. ('cls_out', 'off_out') for box_4c
-    (no angle vectors: avod_fc_layer_utils.py:11-17) or ('off_out',) for the corr head."""
+    """mean of the input crops -> flatten -> fc6.. (ReLU) -> linear output layers
+    (build_output_layers, fusion_fc_layers.py:94-133).  `outputs` names the output layers in
+    params: ('cls_out', 'off_out', 'ang_out') for box_4ca / box_3d, whose ANG_VECS_OUTPUT_SIZE
+    is 2 (avod_fc_layer_utils.py:11-17; the DODT config's avod_box_representation,
+    pyramid_cars_with_aug_dt_5_tracking.config:29), ('cls_out', 'off_out') for box_4c / box_8c,
+    ('off_out',) for the corr head."""
 
-    def __init__(self, ctx, params, outputs=('cls_out', 'off_out'), dtype='f32'):
+    def __init__(self, ctx, params, outputs=('cls_out', 'off_out', 'ang_out'), dtype='f32'):
         names = sorted(k for k in params if k.startswith('fc'))
         self.hidden = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], True, dtype=dtype)
                        for k in names]

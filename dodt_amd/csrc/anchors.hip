@@ -256,11 +256,33 @@ max_fg_logit_kernel(const float* __restrict__ logits, int n_cls, int n,
     out[i] = m;
 }
 
+// dt_evaluator.py:1166-1212 (box_rep 'box_4ca'): the box decoded from four corners knows its
+// heading modulo 90 / 180 degrees only; the regressed angle decides.  float32, unfused, the
+// thresholds as float32(k * pi) like numpy's scalar-with-array comparisons.
+__device__ __forceinline__ void orientation_correct(float b[7], float ori) {
+    const float kPi = (float)M_PI, kTwoPi = (float)(2.0 * M_PI);
+    const float q1 = (float)(0.25 * M_PI), q2 = (float)(0.50 * M_PI), q3 = (float)(0.75 * M_PI);
+    float diff = b[6] - ori;
+    if (diff < -kPi) diff += kTwoPi;
+    if (diff > kPi) diff -= kTwoPi;
+    const bool pos = q1 < diff && diff < q3;
+    const bool neg = -q1 > diff && diff > -q3;
+    if (pos || neg) {
+        const float l = b[3];
+        b[3] = b[4];
+        b[4] = l;
+    }
+    if (pos) b[6] += q2;
+    if (neg) b[6] -= q2;
+    if (fabsf(diff) >= q3) b[6] += kPi;
+    if (b[6] > kPi) b[6] -= kTwoPi;
+}
+
 __global__ void __launch_bounds__(256)
 pack_detections_kernel(const float* __restrict__ boxes_3d, const float* __restrict__ scores,
-                       const float* __restrict__ corr, const int* __restrict__ sel,
-                       const int* __restrict__ d_count, int max_det, float frame_mark,
-                       float* __restrict__ rec, int* __restrict__ count_out) {
+                       const float* __restrict__ orientations, const float* __restrict__ corr,
+                       const int* __restrict__ sel, const int* __restrict__ d_count, int max_det,
+                       float frame_mark, float* __restrict__ rec, int* __restrict__ count_out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = min(*d_count, max_det);
     if (t == 0) *count_out = cnt;
@@ -269,19 +291,35 @@ pack_detections_kernel(const float* __restrict__ boxes_3d, const float* __restri
     float v = 0.0f;
     if (row < cnt) {
         const int src = sel[row];
-        if (col < 7) v = boxes_3d[(size_t)src * 7 + col];
-        else if (col == 7) v = scores[src];
+        if (col == 7) v = scores[src];
         else if (col == 16) v = frame_mark;
-        else if (col >= 9 && corr) {
-            // dt_evaluator.py:1217-1224: the box shifted by (dx, dz, dry) into the next frame
-            const int c = col - 9;
-            v = boxes_3d[(size_t)src * 7 + c];
-            if (c == 0) v += corr[(size_t)src * 3 + 0];
-            else if (c == 2) v += corr[(size_t)src * 3 + 1];
-            else if (c == 6) v += corr[(size_t)src * 3 + 2];
+        else if (col < 7 || (col >= 9 && corr)) {
+            float b[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) b[k] = boxes_3d[(size_t)src * 7 + k];
+            if (orientations) orientation_correct(b, orientations[src]);
+            if (col >= 9) {
+                // dt_evaluator.py:1217-1224: the box shifted by (dx, dz, dry) into the next frame
+                b[0] += corr[(size_t)src * 3 + 0];
+                b[2] += corr[(size_t)src * 3 + 1];
+                b[6] += corr[(size_t)src * 3 + 2];
+            }
+            const int c = col < 7 ? col : col - 9;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k == c) v = b[k];
         }
     }
     rec[t] = v;
+}
+
+// orientation_encoder.py:20-34: atan2(y, x) of the regressed angle vector [x, y]
+__global__ void __launch_bounds__(256)
+angle_vector_to_orientation_kernel(const float* __restrict__ vec, int n,
+                                   const int* __restrict__ d_n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d_n) n = min(n, *d_n);
+    if (i < n) out[i] = atan2f(vec[2 * i + 1], vec[2 * i]);
 }
 
 // calculate_box_3d_info (box_4c_encoder.py:305-366) for one candidate midline
@@ -494,16 +532,26 @@ int dodt_max_fg_logit(dodt_ctx* ctx, const float* d_logits, int n_cls, int n, co
 }
 
 int dodt_pack_detections(dodt_ctx* ctx, const float* d_boxes_3d, const float* d_scores,
-                         const float* d_corr_offsets, const int32_t* d_sel,
-                         const int32_t* d_count, int max_det, float frame_mark,
-                         float* d_rec_out, int32_t* d_count_out) {
+                         const float* d_orientations, const float* d_corr_offsets,
+                         const int32_t* d_sel, const int32_t* d_count, int max_det,
+                         float frame_mark, float* d_rec_out, int32_t* d_count_out) {
     DODT_REQUIRE(ctx && d_boxes_3d && d_scores && d_sel && d_count && d_rec_out && d_count_out &&
                      max_det > 0,
                  "dodt_pack_detections: bad argument");
     hipLaunchKernelGGL(pack_detections_kernel, dim3(dodt::ceil_div(max_det * 17, 256)), dim3(256),
-                       0, ctx->stream, d_boxes_3d, d_scores, d_corr_offsets, d_sel, d_count, max_det,
-                       frame_mark,
-                       d_rec_out, d_count_out);
+                       0, ctx->stream, d_boxes_3d, d_scores, d_orientations, d_corr_offsets, d_sel,
+                       d_count, max_det, frame_mark, d_rec_out, d_count_out);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int dodt_angle_vector_to_orientation(dodt_ctx* ctx, const float* d_angle_vectors, int n,
+                                     const int32_t* d_n, float* d_orientations_out) {
+    DODT_REQUIRE(ctx && d_angle_vectors && d_orientations_out,
+                 "dodt_angle_vector_to_orientation: NULL argument");
+    if (n <= 0) return DODT_OK;
+    hipLaunchKernelGGL(angle_vector_to_orientation_kernel, dim3(dodt::ceil_div(n, 256)), dim3(256),
+                       0, ctx->stream, d_angle_vectors, n, d_n, d_orientations_out);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
 }

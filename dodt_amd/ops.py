@@ -131,12 +131,18 @@ def max_fg_logit(ctx, d_logits, n_cls, n, d_n, d_scores):
         'dodt_max_fg_logit')
 
 
+def angle_vector_to_orientation(ctx, d_angle_vectors, n, d_n, d_orientations):
+    _lib.check(ctx.lib.dodt_angle_vector_to_orientation(
+        ctx.handle, _p(d_angle_vectors), int(n), _p(d_n), _p(d_orientations)),
+        'dodt_angle_vector_to_orientation')
+
+
 def pack_detections(ctx, d_boxes_3d, d_scores, d_sel, d_count, max_det, frame_mark,
-                    d_rec, d_count_out, d_corr_offsets=None):
+                    d_rec, d_count_out, d_corr_offsets=None, d_orientations=None):
     _lib.check(ctx.lib.dodt_pack_detections(
-        ctx.handle, _p(d_boxes_3d), _p(d_scores), _p(d_corr_offsets), _p(d_sel), _p(d_count),
-        int(max_det),
-        float(frame_mark), _p(d_rec), _p(d_count_out)), 'dodt_pack_detections')
+        ctx.handle, _p(d_boxes_3d), _p(d_scores), _p(d_orientations), _p(d_corr_offsets),
+        _p(d_sel), _p(d_count), int(max_det), float(frame_mark), _p(d_rec), _p(d_count_out)),
+        'dodt_pack_detections')
 
 
 def fetch_i32_begin(ctx, d_src, n, slot):

@@ -96,9 +96,15 @@ class FramePairPipeline(object):
         f32, i32 = np.float32, np.int32
         N, P = self.n_all, self.P
         self.rpn_head = self.avod_head = self.corr_head = None
+        rep = cfg.get('box_representation', 'box_4ca')
+        if rep not in ('box_4c', 'box_4ca'):
+            raise NotImplementedError('Regression not implemented for %s' % rep)
+        self.box_4ca = rep == 'box_4ca'
         if head_params is not None:
             self.rpn_head = AnchorPredictor(ctx, head_params['rpn'], dtype=head_dtype)
-            self.avod_head = EarlyFusionFcLayers(ctx, head_params['avod'], dtype=head_dtype)
+            self.avod_head = EarlyFusionFcLayers(
+                ctx, head_params['avod'], dtype=head_dtype,
+                outputs=('cls_out', 'off_out') + (('ang_out',) if self.box_4ca else ()))
             self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'], outputs=('off_out',),
                                                  dtype=head_dtype)
             self.head_scratch = [dict(rpn=self.rpn_head.make_scratch(N),
@@ -129,10 +135,12 @@ class FramePairPipeline(object):
                 boxes_3d=ctx.empty((P, 7), f32), pred_anchors=ctx.empty((P, 6), f32),
                 nms2_boxes=ctx.empty((P, 4), f32), nms2_scores=ctx.empty((P,), f32),
                 det_idx=ctx.empty((MAX_DET,), i32), det_count=ctx.zeros((1,), i32),
-                det_scores=ctx.empty((P,), f32))
+                det_scores=ctx.empty((P,), f32), orientations=ctx.empty((P,), f32))
             if head_params is not None:
                 b.update(rpn_logits=ctx.empty((N, 2), f32), rpn_offsets=ctx.empty((N, 6), f32),
                          cls_logits=ctx.empty((P, 2), f32), offsets_4c=ctx.empty((P, 10), f32))
+                if self.box_4ca:
+                    b.update(angle_vectors=ctx.empty((P, 2), f32))
                 if f % 2 == 0:
                     b.update(corr_rois=ctx.empty((P, ROI, ROI, CORR_CH), f32),
                              corr_offsets=ctx.empty((P, 3), f32))
@@ -193,8 +201,9 @@ class FramePairPipeline(object):
         """Enqueue one step.  Lists of length 2 * pairs_per_step, frame order
         [pair0 f0, pair0 f1, pair1 f0, ...]: d_points[f] (n,4) float32 velodyne xyzi;
         d_images[f] (H,W,3) uint8; heads[f] dict of device arrays rpn_logits (N,2),
-        rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10) [, corr_offsets (P,3) on
-        frame 0 of a pair]; None when the pipeline computes the heads itself (head_params).
+        rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10), angle_vectors (P,2) (box_4ca)
+        [, corr_offsets (P,3) on frame 0 of a pair]; None when the pipeline computes the heads
+        itself (head_params).
         Returns the parity (0/1) of the record buffers this step will fill.  The
         detections of the PREVIOUS step are complete on the main stream when this returns
         (self.d_records / self.fr / self.last_anchor_counts then describe that step);
@@ -318,7 +327,9 @@ class FramePairPipeline(object):
             self._mark(c, st['step'], 'tail%d_crops2' % f)
             if computed:
                 self.avod_head.forward(c, b['bev_rois'], b['img_rois'], self.P, b['top_count'],
-                                       [b['cls_logits'], b['offsets_4c']], scratch['fc'])
+                                       [b['cls_logits'], b['offsets_4c']]
+                                       + ([b['angle_vectors']] if self.box_4ca else []),
+                                       scratch['fc'])
                 self._mark(c, st['step'], 'tail%d_fc2' % f)
                 if f % 2 == 0 and not os.environ.get('DODT_PIPE_NO_CORR'):
                     # T branch: correlate the pair's BEV features, crop with frame 0's
@@ -343,10 +354,17 @@ class FramePairPipeline(object):
                     cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
             # record score = softmax over [background, class] (dt_evaluator.py:1226-1248)
             ops.softmax_fg(c, h['cls_logits'], self.P, b['top_count'], b['det_scores'])
+            # box_4ca: all_orientations = atan2 of the angle vectors (dt_avod_model.py:547-548),
+            # gathered with the boxes by NMS #2's indices (:631-634) inside the record kernel,
+            # which applies the evaluator's heading correction (dt_evaluator.py:1166-1212)
+            if self.box_4ca:
+                ops.angle_vector_to_orientation(c, h['angle_vectors'], self.P, b['top_count'],
+                                                b['orientations'])
             ops.pack_detections(
                 c, b['boxes_3d'], b['det_scores'], b['det_idx'], b['det_count'], MAX_DET,
                 float(f % 2), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
-                self.d_rec_counts.offset(4 * f, (1,), np.int32), d_corr_offsets=corr_offsets)
+                self.d_rec_counts.offset(4 * f, (1,), np.int32), d_corr_offsets=corr_offsets,
+                d_orientations=b['orientations'] if self.box_4ca else None)
             self._mark(c, st['step'], 'tail%d_end' % f)
 
     def sync(self):

@@ -94,14 +94,15 @@ def pyramid_params(in_ch, seed=42):
 def head_outputs(seq, frame, n_anchors, n_proposals):
     """Seeded stand-ins for the dense heads' outputs (for the index-exact parity tests,
     which inject them): RPN objectness logits (A,2) + offsets (A,6); stage-2 class logits
-    (P,2), box_4c offsets (P,10), correlation offsets (P,3)."""
+    (P,2), box_4c offsets (P,10), angle vectors (P,2; box_4ca), correlation offsets (P,3)."""
     rng = np.random.default_rng(frame_seed(seq, frame) + 13)
     return dict(
         rpn_logits=rng.normal(0, 2.0, size=(n_anchors, 2)).astype(np.float32),
         rpn_offsets=rng.normal(0, 0.1, size=(n_anchors, 6)).astype(np.float32),
         cls_logits=rng.normal(0, 2.0, size=(n_proposals, 2)).astype(np.float32),
         offsets_4c=rng.normal(0, 0.1, size=(n_proposals, 10)).astype(np.float32),
-        corr_offsets=rng.normal(0, 0.3, size=(n_proposals, 3)).astype(np.float32))
+        corr_offsets=rng.normal(0, 0.3, size=(n_proposals, 3)).astype(np.float32),
+        angle_vectors=rng.normal(0, 1.0, size=(n_proposals, 2)).astype(np.float32))
 
 
 def _dense(rng, shape, fan_in, bias_std=0.01):
@@ -110,7 +111,7 @@ def _dense(rng, shape, fan_in, bias_std=0.01):
 
 
 def head_params(seed=242, roi=7, feat=32, corr_ch=25, fc_sizes=(2048, 2048, 2048),
-                rpn_fc=256, n_classes=2, off_size=10):
+                rpn_fc=256, n_classes=2, off_size=10, ang_size=2):
     """Random-init weights of the dense heads in the TF variable shapes
     (dt_rpn_model.py:445-537; fusion_fc_layers.py:94-180; avod_corr_layers_builder.py:126-169;
     sizes from pyramid_cars_with_aug_dt_5_corr_tracking.config:64-90)."""
@@ -132,5 +133,6 @@ def head_params(seed=242, roi=7, feat=32, corr_ch=25, fc_sizes=(2048, 2048, 2048
             p[name]['w'] *= np.float32(0.1 if name == 'off_out' else 1.0)
         return p
     return dict(rpn=rpn,
-                avod=stack(roi * roi * feat, (('cls_out', n_classes), ('off_out', off_size))),
+                avod=stack(roi * roi * feat, (('cls_out', n_classes), ('off_out', off_size))
+                           + ((('ang_out', ang_size),) if ang_size else ())),
                 corr=stack(roi * roi * corr_ch, (('off_out', 3),)))

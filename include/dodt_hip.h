@@ -284,16 +284,28 @@ int dodt_gather_rows(dodt_ctx* ctx, const float* d_src, int width, const int32_t
  * (models/dt_avod_model.py:606: tf.reduce_max(all_cls_logits[:, 1:], axis=1)) */
 int dodt_max_fg_logit(dodt_ctx* ctx, const float* d_logits, int n_cls, int n,
                       const int32_t* d_n, float* d_scores_out);
+/* tf_angle_vector_to_orientation (avod/core/orientation_encoder.py:20-34; call site
+ * models/dt_avod_model.py:547-548): atan2(y, x) of the stage-2 head's `ang_out` rows [x, y]
+ * (box_4ca: avod/core/avod_fc_layers/avod_fc_layer_utils.py:11-17).  d_angle_vectors (n,2),
+ * d_orientations_out (n,). */
+int dodt_angle_vector_to_orientation(dodt_ctx* ctx, const float* d_angle_vectors, int n,
+                                     const int32_t* d_n, float* d_orientations_out);
 /* Detection record of one frame, the 17 columns the evaluator writes per box
- * (avod/core/dt_evaluator.py:1217-1257): box_3d(7), score, class index, the box shifted by
- * the correlation head's offsets (x += dx, z += dz, ry += dry; d_corr_offsets (n,3), frame 0
- * of a pair) or 7 zeros (d_corr_offsets NULL: frame 1), frame mark.
- * Rows d_sel[0..*d_count) of boxes_3d / scores; remaining rows of the
- * (max_det,17) output are zeroed; d_count_out[0] = *d_count. */
+ * (get_avod_predicted_boxes_3d_and_scores, avod/core/dt_evaluator.py:1134-1259): box_3d(7),
+ * score, class index, the box shifted by the correlation head's offsets (x += dx, z += dz,
+ * ry += dry; d_corr_offsets (n,3), frame 0 of a pair) or 7 zeros (d_corr_offsets NULL:
+ * frame 1), frame mark.
+ * d_orientations (n,) (may be NULL = box_4c): box_4ca's correction of each selected box by
+ * the regressed angle (:1166-1212) -- difference wrapped to [-pi, pi], l/w swapped and ry
+ * +-pi/2 when it lies in (pi/4, 3pi/4), ry + pi when |difference| >= 3pi/4, ry wrapped above
+ * pi -- applied before the correlation shift, exactly as the evaluator orders them.
+ * Rows d_sel[0..*d_count) of boxes_3d / scores / orientations (the tf.gather by nms_indices,
+ * models/dt_avod_model.py:616-640); remaining rows of the (max_det,17) output are zeroed;
+ * d_count_out[0] = *d_count. */
 int dodt_pack_detections(dodt_ctx* ctx, const float* d_boxes_3d, const float* d_scores,
-                         const float* d_corr_offsets, const int32_t* d_sel,
-                         const int32_t* d_count, int max_det, float frame_mark,
-                         float* d_rec_out, int32_t* d_count_out);
+                         const float* d_orientations, const float* d_corr_offsets,
+                         const int32_t* d_sel, const int32_t* d_count, int max_det,
+                         float frame_mark, float* d_rec_out, int32_t* d_count_out);
 /* Stage-2 decode (models/dt_avod_model.py:464-469,575-603):
  *   anchors_to_box_3d(fix_lw) -> tf_box_3d_to_box_4c -> + offsets ->
  *   tf_box_4c_to_box_3d -> tf_box_3d_to_anchor -> project_to_bev (metres) ->

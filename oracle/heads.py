@@ -44,13 +44,16 @@ def rpn_anchor_predictor(bev_roi, img_roi, p, dtype='f32'):
 
 
 def fusion_fc_early(bev_rois, img_rois, p, dtype='f32'):
-    """fusion_fc_layers.py:136-180 (early fusion, 'mean'), box_4c: no angle output
-    (avod_fc_layer_utils.py:11-17).  rois (P,7,7,32) -> cls logits (P,2), offsets (P,10)."""
+    """fusion_fc_layers.py:136-180 (early fusion, 'mean') + build_output_layers (:94-133).
+    rois (P,7,7,32) -> cls logits (P,2), offsets (P,10) and, when the parameters hold an
+    `ang_out` layer (box_4ca / box_3d: avod_fc_layer_utils.py:11-17), angle vectors (P,2)
+    (else None)."""
     h = mean_fusion(bev_rois, img_rois).reshape(len(bev_rois), -1)
     for name in ('fc6', 'fc7', 'fc8'):
         h = fc(h, p[name]['w'], p[name]['b'], True, dtype)
+    ang = fc(h, p['ang_out']['w'], p['ang_out']['b'], False, dtype) if 'ang_out' in p else None
     return (fc(h, p['cls_out']['w'], p['cls_out']['b'], False, dtype),
-            fc(h, p['off_out']['w'], p['off_out']['b'], False, dtype))
+            fc(h, p['off_out']['w'], p['off_out']['b'], False, dtype), ang)
 
 
 def corr_fc_early(corr_rois, p, dtype='f32'):

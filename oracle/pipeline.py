@@ -35,7 +35,9 @@ def frame_inputs(xyzi, cfg, r0, tr, p2, image_wh):
 def frame_detections(inp, heads, cfg, p2, image_wh, rpn_nms_size, bev_feat=None,
                      img_feat=None, bev_bneck=None, img_bneck=None, frame_mark=0):
     """The graph half after the extractors, with the dense-head outputs given
-    (heads: rpn_logits, rpn_offsets, cls_logits, offsets_4c [, corr_offsets])."""
+    (heads: rpn_logits, rpn_offsets, cls_logits, offsets_4c [, angle_vectors: box_4ca]
+    [, corr_offsets]), and the evaluator's record of the frame
+    (dt_evaluator.py:1134-1259 via oracle.postprocess)."""
     A = len(inp['keep'])
     out = {}
     if bev_bneck is not None:
@@ -64,13 +66,22 @@ def frame_detections(inp, heads, cfg, p2, image_wh, rpn_nms_size, bev_feat=None,
     det = tfops.non_max_suppression_fast(bev_m[:, [1, 0, 3, 2]], s2, cfg['avod_nms_size'],
                                          cfg['avod_nms_iou_thresh'])
     rec = np.zeros((cfg['avod_nms_size'], 17), np.float32)
-    rec[:len(det), :7] = pred[det]
-    # dt_evaluator.py:1217-1257: score = max non-background softmax, class index (0: one
-    # class), the corr-shifted box (frame 0 of the pair; zeros on frame 1), frame mark
+    # dt_avod_model.py:547-548,631-634: orientations of all proposals, gathered by NMS #2;
+    # dt_evaluator.py:1166-1257: box_4ca correction, score = max non-background softmax,
+    # class index (0: one class), the corr-shifted box (frame 0 of the pair; zeros on
+    # frame 1), frame mark
+    from oracle import postprocess as opost
+    final = pred[det].astype(np.float32)
+    ori = None
+    if heads.get('angle_vectors') is not None:
+        ori = oboxes.angle_vector_to_orientation(heads['angle_vectors'][:n], np.float32)
+        out['orientations'] = ori
+        final = opost.orientation_corrected_boxes_3d(final, ori[det])
+    rec[:len(det), :7] = final
     rec[:len(det), 7] = tfops.softmax2(heads['cls_logits'][:n])[det, 1]
     if heads.get('corr_offsets') is not None and frame_mark == 0:
         off = heads['corr_offsets'][:n][det].astype(np.float32)
-        shifted = pred[det].astype(np.float32).copy()
+        shifted = final.copy()
         shifted[:, 0] += off[:, 0]
         shifted[:, 2] += off[:, 1]
         shifted[:, 6] += off[:, 2]
@@ -104,10 +115,11 @@ def pair_detections_computed(inps, feats, head_params, cfg, p2, image_wh, rpn_nm
         _, top_bev = oboxes.project_to_bev(top_anchors, cfg['bev_extents'], np.float32)
         _, top_img = oboxes.project_to_image_space(top_anchors, p2, [image_wh[1], image_wh[0]],
                                                    dtype=np.float32)
-        cls, o4c = oheads.fusion_fc_early(
+        cls, o4c, ang = oheads.fusion_fc_early(
             tfops.crop_and_resize(bev_feat, top_bev[:, [1, 0, 3, 2]], 7, 7),
             tfops.crop_and_resize(img_feat, top_img[:, [1, 0, 3, 2]], 7, 7), head_params['avod'])
-        heads = dict(rpn_logits=obj, rpn_offsets=off, cls_logits=cls, offsets_4c=o4c)
+        heads = dict(rpn_logits=obj, rpn_offsets=off, cls_logits=cls, offsets_4c=o4c,
+                     angle_vectors=ang)
         if f == 0:
             heads['corr_offsets'] = oheads.corr_fc_early(
                 tfops.crop_and_resize(corr_map, top_bev[:, [1, 0, 3, 2]], 7, 7),

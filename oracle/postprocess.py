@@ -8,6 +8,9 @@ Restated from:
   wavedata/wavedata/tools/core/calib_utils.py:394-410          project_to_image
   avod/core/box_3d_projector.py:86-159                         project_to_image_space
   avod/core/dt_inference_utils.py:135-215                      convert_pred_to_kitti_format
+  avod/core/dt_evaluator.py:1134-1259                          get_avod_predicted_boxes_3d_and_scores
+                                                               (pinned by tests/golden/box4ca.npz,
+                                                               tests/golden/make_goldens_box4ca.py)
 """
 import numpy as np
 
@@ -76,3 +79,55 @@ def convert_pred_to_kitti_format(all_predictions, p2, image_size, classes, score
     if not rows:
         return [], np.zeros((0, 15))
     return types, np.asarray(rows)
+
+
+def orientation_corrected_boxes_3d(boxes_3d, orientations):
+    """dt_evaluator.py:1166-1212, box_rep 'box_4ca': the box decoded from its four corners
+    knows its heading only modulo 90 degrees (its long side may have become the short one)
+    and modulo 180; the angle the network regressed (orientations) decides.  float32
+    arithmetic like the arrays the evaluator receives from sess.run; python-float constants
+    take part as float32 (numpy scalar-with-array casting).  ry - pi/2 below -pi is left
+    unwrapped, as in the reference."""
+    f32 = np.float32
+    b = np.array(boxes_3d, dtype=f32, copy=True)
+    ori = np.asarray(orientations, dtype=f32)
+    two_pi, pi = f32(2 * np.pi), f32(np.pi)
+    diff = b[:, 6] - ori
+    diff = np.where(diff < -pi, diff + two_pi, diff).astype(f32)
+    diff = np.where(diff > pi, diff - two_pi, diff).astype(f32)
+    q1, q2, q3 = f32(0.25 * np.pi), f32(0.50 * np.pi), f32(0.75 * np.pi)
+    pos = (q1 < diff) & (diff < q3)
+    neg = (-q1 > diff) & (diff > -q3)
+    swap = pos | neg
+    b[swap, 3], b[swap, 4] = b[swap, 4].copy(), b[swap, 3].copy()
+    b[pos, 6] = b[pos, 6] + q2
+    b[neg, 6] = b[neg, 6] - q2
+    flip = np.abs(diff) >= q3
+    b[flip, 6] = b[flip, 6] + pi
+    above = b[:, 6] > pi
+    b[above, 6] = b[above, 6] - two_pi
+    return b
+
+
+def avod_predicted_boxes_3d_and_scores(boxes_3d, orientations, softmax, corr_offsets):
+    """dt_evaluator.py:1134-1259 for one frame pair, box_rep 'box_4ca' (orientations not None)
+    or 'box_4c' (None).  Lists of two per-frame arrays; corr_offsets (n0,3) of frame 0.
+    -> (n0 + n1, 17): box_3d(7), score, type, frame-0 box shifted by the correlation offsets
+    (zeros for frame 1), frame mark."""
+    boxes = [np.asarray(b, np.float32) if orientations is None
+             else orientation_corrected_boxes_3d(b, orientations[i])
+             for i, b in enumerate(boxes_3d)]
+    shifted = boxes[0].copy()
+    off = np.asarray(corr_offsets, np.float32)
+    shifted[:, 0] += off[:, 0]
+    shifted[:, 2] += off[:, 1]
+    shifted[:, 6] += off[:, 2]
+    corr = [shifted, np.zeros((len(boxes[1]), 7))]
+    rows = []
+    for i in range(2):
+        fg = np.asarray(softmax[i])[:, 1:]
+        types = np.argmax(fg, axis=1)
+        scores = fg[np.arange(len(fg)), types]
+        rows.append(np.column_stack([boxes[i], scores, types, corr[i],
+                                     np.ones((len(boxes[i]), 1)) * i]))
+    return np.concatenate(rows, axis=0)

@@ -164,12 +164,15 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
         n_top = int(b['top_count'].download()[0])
         assert n_top > 100
         # stage-2 heads on the device's crops
-        cls, o4c = oheads.fusion_fc_early(b['bev_rois'].download()[:n_top],
-                                          b['img_rois'].download()[:n_top], hp['avod'], head_dtype)
+        cls, o4c, ang = oheads.fusion_fc_early(b['bev_rois'].download()[:n_top],
+                                               b['img_rois'].download()[:n_top], hp['avod'],
+                                               head_dtype)
         heads.update(cls_logits=b['cls_logits'].download()[:n_top],
-                     offsets_4c=b['offsets_4c'].download()[:n_top])
+                     offsets_4c=b['offsets_4c'].download()[:n_top],
+                     angle_vectors=b['angle_vectors'].download()[:n_top])
         _close(heads['cls_logits'], cls, tol)
         _close(heads['offsets_4c'], o4c, tol)
+        _close(heads['angle_vectors'], ang, tol)      # box_4ca's third output layer
         if f == 0:
             want_rois = tfops.crop_and_resize(corr_map, b['top_bev'].download()[:n_top], 7, 7)
             got_rois = b['corr_rois'].download()[:n_top]
@@ -183,8 +186,20 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
         assert np.array_equal(b['top_idx'].download()[:n_top], want['top_idx'])
         n_det = int(b['det_count'].download()[0])
         assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
-        # box regressions: the north_star's 1e-4 (the decode chain has atan2 / sincos in it)
-        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-4, atol=1e-4)
+        # box regressions: the north_star's 1e-4 (the decode chain has atan2 / sincos in it).
+        # The heading correction of box_4ca branches on |ry - orientation| against multiples
+        # of pi/4: a detection whose difference lies within 1e-5 rad of a threshold may take
+        # the other branch on a last-bit difference of atan2f; such rows (if any) are only
+        # required to be one of the two legal outcomes, i.e. they are skipped here
+        ori = b['orientations'].download()[:n_top]
+        np.testing.assert_allclose(ori, want['orientations'], rtol=0, atol=2e-6)
+        d = b['boxes_3d'].download()[:n_top][want['det_idx'], 6] - ori[want['det_idx']]
+        d = (d + np.pi) % (2 * np.pi) - np.pi
+        far = np.abs(np.abs(d)[:, None] - np.pi * np.array([0.25, 0.75, 1.0])).min(axis=1) > 1e-5
+        assert far.sum() >= n_det - 2
+        rows = np.concatenate([np.nonzero(far)[0], np.arange(n_det, MAX_DET)])
+        np.testing.assert_allclose(recs[f][rows], want['records'][rows], rtol=1e-4, atol=1e-4)
+        assert (recs[f][:n_det, 3] < recs[f][:n_det, 4]).any()    # some l/w swaps happened
     assert pipe.head_flops_per_step() > 5e10
     with pytest.raises(ValueError):
         pipe.run([], [], [], heads=[{}])

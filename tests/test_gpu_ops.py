@@ -170,3 +170,54 @@ def test_softmax_and_gather(ctx):
     d_g = ctx.empty((300, 6), np.float32)
     ops.gather_rows(ctx, ctx.array(src), 6, ctx.array(idx), 300, None, d_g)
     assert np.array_equal(d_g.download(), src[idx])
+
+
+def test_box_4ca_records_match_reference_goldens(ctx, golden_dir):
+    """dodt_pack_detections with orientations against the reference's own
+    get_avod_predicted_boxes_3d_and_scores (avod/core/dt_evaluator.py:1134-1259, box_4ca;
+    tests/golden/make_goldens_box4ca.py): heading correction, l/w swap, correlation shift,
+    every column -- bit for bit (float32 arithmetic on both sides, thresholds included)."""
+    from dodt_amd.core import orientation_encoder as gpu_orient
+    g = np.load(os.path.join(golden_dir, 'box4ca.npz'))
+    for c in range(int(g['n_cases'])):
+        want = g['c%d_records' % c]
+        row = 0
+        for f in range(2):
+            boxes = g['c%d_boxes_3d_%d' % (c, f)]
+            ori = g['c%d_orientations_%d' % (c, f)]
+            scores = g['c%d_softmax_%d' % (c, f)][:, 1]
+            got = gpu_orient.predicted_boxes_3d_and_scores(
+                boxes, scores, ori, g['c%d_corr_offsets' % c] if f == 0 else None, f, ctx=ctx)
+            assert np.array_equal(got.astype(np.float64), want[row:row + len(boxes)]), (c, f)
+            row += len(boxes)
+    # box_4c (no orientations): boxes pass through unchanged
+    boxes, scores = g['c0_boxes_3d_0'], g['c0_softmax_0'][:, 1]
+    plain = gpu_orient.predicted_boxes_3d_and_scores(boxes, scores, None, None, 1, ctx=ctx)
+    assert np.array_equal(plain[:, :7], boxes) and not plain[:, 9:16].any()
+    # gathered by selection indices, padded with zero rows, count clipped to max_det
+    n = len(boxes)
+    sel = np.random.default_rng(3).permutation(n)[:40].astype(np.int32)
+    d_rec, d_cnt = ctx.empty((50, 17), np.float32), ctx.empty((1,), np.int32)
+    ops.pack_detections(ctx, ctx.array(boxes), ctx.array(scores), ctx.array(sel),
+                        ctx.array(np.array([40], np.int32)), 50, 0.0, d_rec, d_cnt,
+                        d_corr_offsets=ctx.array(g['c0_corr_offsets']),
+                        d_orientations=ctx.array(g['c0_orientations_0']))
+    rec = d_rec.download()
+    assert d_cnt.download()[0] == 40 and not rec[40:].any()
+    assert np.array_equal(rec[:40].astype(np.float64), g['c0_records'][sel])
+
+
+def test_angle_vector_to_orientation(ctx):
+    """avod/core/orientation_encoder.py:20-34 and the known answers of
+    orientation_encoder_test.py:26-87 (atan2f against numpy's float32 arctan2: 1 ulp)."""
+    from dodt_amd.core import orientation_encoder as gpu_orient
+    rng = np.random.default_rng(12)
+    v = rng.normal(size=(3000, 2)).astype(np.float32)
+    v[:6] = [[1, 0], [0, 1], [-1, 0], [0, -1], [0.70710678, 0.70710678], [-1, -1e-9]]
+    got = gpu_orient.tf_angle_vector_to_orientation(v, ctx=ctx)
+    want = oboxes.angle_vector_to_orientation(v, np.float32)
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(got[:5], [0, np.pi / 2, np.pi, -np.pi / 2, np.pi / 4], atol=1e-6)
+    assert len(gpu_orient.tf_angle_vector_to_orientation(np.zeros((0, 2)), ctx=ctx)) == 0
+    with pytest.raises(ValueError):
+        gpu_orient.tf_angle_vector_to_orientation(np.zeros((4, 3)), ctx=ctx)

@@ -98,8 +98,11 @@ def test_heads_shapes_and_fusion():
     assert np.array_equal(obj, obj2) and np.array_equal(off, off2)
     r1 = rng.uniform(size=(4, 7, 7, 32)).astype(np.float32)
     r2 = rng.uniform(size=(4, 7, 7, 32)).astype(np.float32)
-    cls, o4c = oheads.fusion_fc_early(r1, r2, hp['avod'])
+    cls, o4c, ang = oheads.fusion_fc_early(r1, r2, hp['avod'])
     assert cls.shape == (4, 2) and o4c.shape == (4, 10)
+    assert ang.shape == (4, 2)       # box_4ca: ANG_VECS_OUTPUT_SIZE 2 (avod_fc_layer_utils.py:11-17)
+    hp4c = synth.head_params(fc_sizes=(64, 64, 64), ang_size=0)     # box_4c: no angle layer
+    assert oheads.fusion_fc_early(r1, r2, hp4c['avod'])[2] is None
     assert oheads.corr_fc_early(rng.uniform(size=(4, 7, 7, 25)).astype(np.float32),
                                 hp['corr']).shape == (4, 3)
 

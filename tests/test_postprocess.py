@@ -58,3 +58,24 @@ def test_kitti_rows_from_records():
     np.testing.assert_allclose(r0[7:10], np.round([first[5], first[4], first[3]], 3))
     assert host.convert_pred_to_kitti_format(rec, p2, size, ['Car'], 2.0) == []
     assert opost.convert_pred_to_kitti_format(rec, p2, size, ['Car'], 2.0)[0] == []
+
+
+B4 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'box4ca.npz'))
+
+
+def test_oracle_box_4ca_records_match_reference_goldens():
+    """avod/core/dt_evaluator.py:1134-1259 run by tests/golden/make_goldens_box4ca.py:
+    every column of every record, bit for bit (float32 arithmetic, thresholds included)."""
+    for c in range(int(B4['n_cases'])):
+        boxes = [B4['c%d_boxes_3d_%d' % (c, f)] for f in range(2)]
+        ori = [B4['c%d_orientations_%d' % (c, f)] for f in range(2)]
+        sm = [B4['c%d_softmax_%d' % (c, f)] for f in range(2)]
+        got = opost.avod_predicted_boxes_3d_and_scores(boxes, ori, sm, B4['c%d_corr_offsets' % c])
+        want = B4['c%d_records' % c]
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), c
+    # the thresholds are exercised: some rows swapped, some flipped, some untouched
+    want, b0 = B4['c1_records'], B4['c1_boxes_3d_0']
+    n0 = len(b0)
+    assert 0 < (want[:n0, 3] != b0[:, 3]).sum() < n0
+    assert (np.abs(want[:n0, 6] - b0[:, 6]) > 3.0).any()
