@@ -204,11 +204,14 @@ def main():
         # event i fires when step i's convs and step i-1's tail are done, so the deltas show
         # a slow fill / drain step or a clock ramp that the single wall-clock window hides
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 2)]
+        host_ms = []
         t0 = time.perf_counter()
         evs[0].record()
         for i in range(steps):
+            th = time.perf_counter()
             step(i)
             evs[i + 1].record()
+            host_ms.append((time.perf_counter() - th) * 1e3)
         host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3   # host side of a step
         drain()
         evs[steps + 1].record()
@@ -245,7 +248,7 @@ def main():
             ctx.wait_for(pipe.img_ctx)
         both_ms = ctx.timer_stop() / reps
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
-                   step_ms=step_ms,
+                   step_ms=step_ms, host_ms=host_ms,
                    both_ms=both_ms,
                    flops=pipe.flops_per_step(), head_gflop=pipe.head_flops_per_step() / 1e9,
                    conv_bytes=pipe.conv_bytes_per_step(),
@@ -253,6 +256,13 @@ def main():
         pipe.close()
         return res
 
+    import gc
+    if os.environ.get('DODT_BENCH_GC', 'freeze') == 'freeze':
+        # everything allocated so far (torch, numpy, the package) leaves the collector's
+        # generations: a full collection of that heap in the middle of a 0.1 s timed window
+        # would stall the enqueueing thread for tens of ms
+        gc.collect()
+        gc.freeze()
     m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype)
     elapsed, host_enqueue_ms, conv_ms, reps = m['elapsed'], m['host_enqueue_ms'], m['conv_ms'], m['reps']
     alt = None
@@ -331,7 +341,9 @@ def main():
                         'median': round(float(np.median(m['step_ms'][:-1])), 3),
                         'max': round(max(m['step_ms'][:-1]), 3),
                         'drain': round(m['step_ms'][-1], 3),
-                        'all': [round(v, 2) for v in m['step_ms']]},
+                        'all': [round(v, 2) for v in m['step_ms']],
+                        'host_max': round(max(m['host_ms']), 3),
+                        'host_median': round(float(np.median(m['host_ms'])), 3)},
             'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_dtype, 'data': 'synthetic',
             'head_dtype': args.head_dtype,
