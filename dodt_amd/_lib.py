@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdodt_hip.so')
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 PTS_VELO_XYZI, PTS_CAM_3XN = 0, 1
 EXTRACTOR_VGG_PYR = 0
+EXTRACTOR_VGG = 1
 EXTRACTOR_SHARED_GPU = 0x100
 EXTRACTOR_BF16 = 0x200
 EXTRACTOR_SPLIT = 0x400
@@ -92,6 +93,7 @@ SIGNATURES = {
     'dodt_extractor_read_activation': (_i, [_vp, C.c_char_p, _vp,
                                             C.POINTER(_i), C.POINTER(_i),
                                             C.POINTER(_i)]),
+    'dodt_extractor_output_shape': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'dodt_extractor_flops': (_d, [_vp]),
     'dodt_extractor_bytes': (_d, [_vp]),
     'dodt_crop_and_resize': (_i, [_vp, _pf, _i, _i, _i, _pf, _i, _pi32, _i, _i,

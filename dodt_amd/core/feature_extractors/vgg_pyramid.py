@@ -8,11 +8,12 @@ import ctypes as C
 
 import numpy as np
 
-from dodt_amd import _lib, device, synth
+from dodt_amd import _lib, device
 
 
 class _VggPyr(object):
     PAD_TOP = 0
+    KIND = _lib.EXTRACTOR_VGG_PYR
 
     def __init__(self, extractor_config=None, ctx=None, shared_gpu=False, conv_dtype='f32'):
         """shared_gpu: other streams keep the GPU busy beside this net (the frame-pair
@@ -41,7 +42,7 @@ class _VggPyr(object):
         hnd = C.c_void_p()
         _lib.check(self._ctx.lib.dodt_extractor_create(
             self._ctx.handle,
-            _lib.EXTRACTOR_VGG_PYR | (_lib.EXTRACTOR_SHARED_GPU if self._shared_gpu else 0)
+            self.KIND | (_lib.EXTRACTOR_SHARED_GPU if self._shared_gpu else 0)
             | (_lib.EXTRACTOR_BF16 if self._bf16 else 0)
             | (_lib.EXTRACTOR_SPLIT if self._split else 0),
             h, w, c, self.PAD_TOP,
@@ -95,6 +96,13 @@ class _VggPyr(object):
             self._handle, C.byref(p), C.byref(stride)), 'dodt_extractor_input')
         return p.value, stride.value
 
+    def output_shape(self):
+        """(h, w, c) of the feature map a forward returns (needs a built extractor)."""
+        h, w, c = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._ctx.lib.dodt_extractor_output_shape(
+            self._handle, C.byref(h), C.byref(w), C.byref(c)), 'dodt_extractor_output_shape')
+        return h.value, w.value, c.value
+
     def flops(self):
         return self._ctx.lib.dodt_extractor_flops(self._handle)
 
@@ -131,8 +139,9 @@ class _VggPyr(object):
         self._ensure(b, h, w, c)
         ctx = self._ctx
         d_in = ctx.array(x)
-        d_feat = ctx.empty((b, h, w, 32), np.float32)
-        d_bn = ctx.empty((b, h, w, 1), np.float32) if with_bottleneck else None
+        oh, ow, oc = self.output_shape()
+        d_feat = ctx.empty((b, oh, ow, oc), np.float32)
+        d_bn = ctx.empty((b, oh, ow, 1), np.float32) if with_bottleneck else None
         self.forward_device(d_in, d_feat, d_bn)
         end_points = {}
         if with_bottleneck:

@@ -29,6 +29,7 @@ using dodt::KernelVariant;
 using dodt::Inst;
 using dodt::InstSmall;
 using dodt::tail_only;
+using dodt::f32x4;
 
 const std::vector<KernelVariant>& variants() {
     static const std::vector<KernelVariant> v = {
@@ -171,6 +172,59 @@ copy_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long 
     dst[f * dst_frame_stride4 + i] = src[f * src_frame_stride4 + i];
 }
 
+// tf.image.resize_bilinear (TF 1.3 legacy sampling, align_corners = False: src = dst * in/out)
+// of the CB8 conv4_3 map to the NHWC feature map the plain-VGG extractors return
+// (bev_vgg.py:102-112, img_vgg.py:104-114), with the 1x1 bottleneck (rpn_model.py:251-267)
+// on the upsampled pixel fused in.  C / 4 lanes per output pixel, one float4 of channels each:
+// a wave stores 1 KB of contiguous NHWC output per instruction; the source map (9-12 MB)
+// stays in L2.  HBM-bound on the output write.  float32, unfused, TF's operation order.
+template <int LPP>   // lanes per pixel = C / 4
+__global__ void __launch_bounds__(256)
+upsample_bilinear_cb8_kernel(const float* __restrict__ in, int IH, int IW, long long in_frame_stride,
+                             int OH, int OW, int frames, float* __restrict__ out,
+                             const float* __restrict__ bneck_w, float bneck_scale,
+                             float bneck_shift, float* __restrict__ bneck_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pix = t / LPP;
+    const int l = (int)(t % LPP);
+    const long long n_pix = (long long)frames * OH * OW;
+    const bool ok = pix < n_pix;
+    float dot = 0.0f;
+    if (ok) {
+        const int f = (int)(pix / ((long long)OH * OW));
+        const int r = (int)(pix - (long long)f * OH * OW);
+        const int oy = r / OW, ox = r - oy * OW;
+        const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+        const float fy = (float)oy * sy, fx = (float)ox * sx;
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = min(y0 + 1, IH - 1), x1 = min(x0 + 1, IW - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* base = in + (size_t)f * in_frame_stride + (size_t)(l >> 1) * IH * IW * 8 +
+                            (l & 1) * 4;
+        const f32x4 tl = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * IW + x0) * 8);
+        const f32x4 tr = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * IW + x1) * 8);
+        const f32x4 bl = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * IW + x0) * 8);
+        const f32x4 br = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * IW + x1) * 8);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float top = tl[k] + (tr[k] - tl[k]) * lx;
+            const float bot = bl[k] + (br[k] - bl[k]) * lx;
+            v[k] = top + (bot - top) * ly;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * (LPP * 4) + l * 4) = v;
+        if (bneck_out) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(bneck_w + l * 4);
+            dot = ((v[0] * w[0] + v[1] * w[1]) + v[2] * w[2]) + v[3] * w[3];
+        }
+    }
+    if (bneck_out) {
+#pragma unroll
+        for (int m = 1; m < LPP; m <<= 1) dot += __shfl_xor(dot, m, 64);
+        if (ok && l == 0) bneck_out[pix] = fmaxf(dot * bneck_scale + bneck_shift, 0.0f);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // extractor object
 // ---------------------------------------------------------------------------
@@ -211,6 +265,8 @@ enum Buf { X0, C1A, CAT1, P1, C2A, CAT2, P2, C3A, C3B, CAT3, P3, C4A, C4B, C4C, 
 struct dodt_extractor {
     dodt_ctx* ctx = nullptr;
     int in_h = 0, in_w = 0, in_c = 0, pad_top = 0, batch = 0;
+    int kind = DODT_EXTRACTOR_VGG_PYR;
+    int out_h = 0, out_w = 0, out_c = 32;   // the returned feature map
     bool bf16 = false;  // conv path on bf16 MFMA (fp32 accumulate, fp32 BN/ReLU, bf16 maps)
     int parts = 1;      // 2: split mode (hi + lo bf16 maps and weights, three MFMAs per term)
     int H = 0, W = 0;  // padded input size
@@ -406,35 +462,55 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     // (the bf16 kernels have no quarter-size instantiations: single launches)
     const bool shared_gpu = (kind & DODT_EXTRACTOR_SHARED_GPU) != 0 || bf16;
     kind &= ~(DODT_EXTRACTOR_SHARED_GPU | DODT_EXTRACTOR_BF16 | DODT_EXTRACTOR_SPLIT);
-    DODT_REQUIRE(kind == DODT_EXTRACTOR_VGG_PYR, "dodt_extractor_create: unknown kind %d", kind);
+    DODT_REQUIRE(kind == DODT_EXTRACTOR_VGG_PYR || kind == DODT_EXTRACTOR_VGG,
+                 "dodt_extractor_create: unknown kind %d", kind);
+    const bool plain = kind == DODT_EXTRACTOR_VGG;
     DODT_REQUIRE(in_h > 0 && in_w > 0 && in_c >= 2 && in_c % 2 == 0 && pad_top >= 0 && batch >= 1,
                  "dodt_extractor_create: bad sizes (in_c must be even)");
     const int H = in_h + pad_top, W = in_w;
-    DODT_REQUIRE(H % 8 == 0 && W % 8 == 0,
-                 "dodt_extractor_create: padded input %dx%d must be divisible by 8 "
-                 "(three 2x2 pools, three stride-2 upconvs)", H, W);
+    if (plain) {
+        DODT_REQUIRE(!bf16, "dodt_extractor_create: the plain VGG extractor is fp32 only");
+        DODT_REQUIRE(pad_top == 0 && H >= 16 && W >= 16,
+                     "dodt_extractor_create: plain VGG takes no top padding and >= 16x16 inputs");
+    } else {
+        DODT_REQUIRE(H % 8 == 0 && W % 8 == 0,
+                     "dodt_extractor_create: padded input %dx%d must be divisible by 8 "
+                     "(three 2x2 pools, three stride-2 upconvs)", H, W);
+    }
     for (const KernelVariant& v : variants()) DODT_HIP_CHECK(v.prepare());
 
     dodt_extractor* ex = new dodt_extractor();
     ex->ctx = ctx;
+    ex->kind = kind;
     ex->in_h = in_h; ex->in_w = in_w; ex->in_c = in_c; ex->pad_top = pad_top; ex->batch = batch;
     ex->H = H; ex->W = W;
     ex->bf16 = bf16;
     ex->parts = split ? 2 : 1;
     auto setb = [&](int id, int h, int w, int c) { ex->buf[id].H = h; ex->buf[id].W = w; ex->buf[id].C = c; };
+    // VALID 2x2 pools floor odd sizes (plain VGG: 175 -> 87, 795 -> 397 -> 198)
+    const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, H8 = H4 / 2, W8 = W4 / 2;
     setb(X0, H, W, in_c);
-    setb(C1A, H, W, 32); setb(CAT1, H, W, 64); setb(P1, H / 2, W / 2, 32);
-    setb(C2A, H / 2, W / 2, 64); setb(CAT2, H / 2, W / 2, 128); setb(P2, H / 4, W / 4, 64);
-    setb(C3A, H / 4, W / 4, 128); setb(C3B, H / 4, W / 4, 128); setb(CAT3, H / 4, W / 4, 256);
-    setb(P3, H / 8, W / 8, 128);
-    setb(C4A, H / 8, W / 8, 256); setb(C4B, H / 8, W / 8, 256); setb(C4C, H / 8, W / 8, 256);
-    setb(F3, H / 4, W / 4, 64); setb(F2, H / 2, W / 2, 32); setb(F1, H, W, 32);
+    setb(C1A, H, W, 32); setb(CAT1, H, W, plain ? 32 : 64); setb(P1, H2, W2, 32);
+    setb(C2A, H2, W2, 64); setb(CAT2, H2, W2, plain ? 64 : 128); setb(P2, H4, W4, 64);
+    setb(C3A, H4, W4, 128); setb(C3B, H4, W4, 128); setb(CAT3, H4, W4, plain ? 128 : 256);
+    setb(P3, H8, W8, 128);
+    setb(C4A, H8, W8, 256); setb(C4B, H8, W8, 256); setb(C4C, H8, W8, 256);
+    if (!plain) { setb(F3, H4, W4, 64); setb(F2, H2, W2, 32); setb(F1, H, W, 32); }
+    if (plain) {
+        // bev_vgg.py:102-112: resize_bilinear to input_pixel_size / 8 * upsampling_multiplier (4),
+        // a float pair that TF casts to int32 (350 x 400 for 700 x 800, 240 x 795 for 480 x 1590)
+        ex->out_h = (int)((double)in_h / 8.0 * 4.0);
+        ex->out_w = (int)((double)in_w / 8.0 * 4.0);
+        ex->out_c = 256;
+    } else {
+        ex->out_h = in_h; ex->out_w = in_w; ex->out_c = 32;
+    }
     for (int i = 0; i < NBUF; ++i) {
         ex->buf[i].bf16 = bf16 && i != X0 && i != F1;
         ex->buf[i].parts = ex->buf[i].bf16 ? ex->parts : 1;
     }
     for (int i = 0; i < NBUF; ++i) {
-        if (i == F1) continue;  // the last layer writes into the caller's buffer
+        if (i == F1 || ex->buf[i].H == 0) continue;  // F1: written into the caller's buffer
         const size_t bytes = ex->buf[i].frame_floats() * batch * ex->buf[i].parts * sizeof(float);
         hipError_t e = hipMalloc(&ex->buf[i].ptr, bytes);
         if (e != hipSuccess) {
@@ -460,20 +536,22 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
     };
     add("conv1_1", false, H, W, in_c, 32, X0, 0, C1A, 0);
     add("conv1_2", false, H, W, 32, 32, C1A, 0, CAT1, 0);
-    add("conv2_1", false, H / 2, W / 2, 32, 64, P1, 0, C2A, 0);
-    add("conv2_2", false, H / 2, W / 2, 64, 64, C2A, 0, CAT2, 0);
-    add("conv3_1", false, H / 4, W / 4, 64, 128, P2, 0, C3A, 0);
-    add("conv3_2", false, H / 4, W / 4, 128, 128, C3A, 0, C3B, 0);
-    add("conv3_3", false, H / 4, W / 4, 128, 128, C3B, 0, CAT3, 0);
-    add("conv4_1", false, H / 8, W / 8, 128, 256, P3, 0, C4A, 0);
-    add("conv4_2", false, H / 8, W / 8, 256, 256, C4A, 0, C4B, 0);
-    add("conv4_3", false, H / 8, W / 8, 256, 256, C4B, 0, C4C, 0);
-    add("upconv3", true, H / 8, W / 8, 256, 128, C4C, 0, CAT3, 128);
-    add("pyramid_fusion3", false, H / 4, W / 4, 256, 64, CAT3, 0, F3, 0);
-    add("upconv2", true, H / 4, W / 4, 64, 64, F3, 0, CAT2, 64);
-    add("pyramid_fusion2", false, H / 2, W / 2, 128, 32, CAT2, 0, F2, 0);
-    add("upconv1", true, H / 2, W / 2, 32, 32, F2, 0, CAT1, 32);
-    add("pyramid_fusion1", false, H, W, 64, 32, CAT1, 0, F1, 0);
+    add("conv2_1", false, H2, W2, 32, 64, P1, 0, C2A, 0);
+    add("conv2_2", false, H2, W2, 64, 64, C2A, 0, CAT2, 0);
+    add("conv3_1", false, H4, W4, 64, 128, P2, 0, C3A, 0);
+    add("conv3_2", false, H4, W4, 128, 128, C3A, 0, C3B, 0);
+    add("conv3_3", false, H4, W4, 128, 128, C3B, 0, CAT3, 0);
+    add("conv4_1", false, H8, W8, 128, 256, P3, 0, C4A, 0);
+    add("conv4_2", false, H8, W8, 256, 256, C4A, 0, C4B, 0);
+    add("conv4_3", false, H8, W8, 256, 256, C4B, 0, C4C, 0);
+    if (!plain) {
+        add("upconv3", true, H8, W8, 256, 128, C4C, 0, CAT3, 128);
+        add("pyramid_fusion3", false, H4, W4, 256, 64, CAT3, 0, F3, 0);
+        add("upconv2", true, H4, W4, 64, 64, F3, 0, CAT2, 64);
+        add("pyramid_fusion2", false, H2, W2, 128, 32, CAT2, 0, F2, 0);
+        add("upconv1", true, H2, W2, 32, 32, F2, 0, CAT1, 32);
+        add("pyramid_fusion1", false, H, W, 64, 32, CAT1, 0, F1, 0);
+    }
     for (const Layer& l : ex->layers) {
         if (l.variant < 0) {
             dodt::set_error("dodt_extractor_create: no kernel variant for layer %s (%dx%d %d->%d)",
@@ -537,10 +615,11 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     DODT_REQUIRE(ex && name && w && beta && mean && var, "dodt_extractor_set_layer: NULL argument");
     hipStream_t s = ex->ctx->stream;
     if (std::strcmp(name, "bottleneck") == 0) {
-        DODT_REQUIRE(kh == 1 && kw == 1 && c_a == 32 && c_b == 1,
-                     "bottleneck must be (1,1,32,1), got (%d,%d,%d,%d)", kh, kw, c_a, c_b);
-        if (!ex->d_bneck_w) DODT_HIP_CHECK(hipMalloc(&ex->d_bneck_w, 32 * sizeof(float)));
-        DODT_HIP_CHECK(hipMemcpyAsync(ex->d_bneck_w, w, 32 * sizeof(float), hipMemcpyHostToDevice, s));
+        const int fc = ex->out_c;   // 32 (pyramid) or 256 (plain VGG: rpn_model.py:251-267)
+        DODT_REQUIRE(kh == 1 && kw == 1 && c_a == fc && c_b == 1,
+                     "bottleneck must be (1,1,%d,1), got (%d,%d,%d,%d)", fc, kh, kw, c_a, c_b);
+        if (!ex->d_bneck_w) DODT_HIP_CHECK(hipMalloc(&ex->d_bneck_w, fc * sizeof(float)));
+        DODT_HIP_CHECK(hipMemcpyAsync(ex->d_bneck_w, w, fc * sizeof(float), hipMemcpyHostToDevice, s));
         DODT_HIP_CHECK(hipStreamSynchronize(s));
         const float inv = 1.0f / std::sqrt(var[0] + 0.001f);
         ex->bneck_scale = inv;
@@ -670,6 +749,20 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
     RUN("conv3_1"); RUN("conv3_2"); RUN_POOLED("conv3_3", CAT3, P3);
 #undef RUN_POOLED
     RUN("conv4_1"); RUN("conv4_2"); RUN("conv4_3");
+    if (ex->kind == DODT_EXTRACTOR_VGG) {
+        // bev_vgg.py:102-112 / img_vgg.py:104-114: 4x bilinear upsampling of conv4_3, and the
+        // 256 -> 1 bottleneck of the RPN (rpn_model.py:251-267) on the upsampled map
+        const Buffer& c4 = ex->buf[C4C];
+        const long long n_pix = (long long)ex->batch * ex->out_h * ex->out_w;
+        constexpr int kLpp = 64;   // 256 channels / 4
+        hipLaunchKernelGGL(upsample_bilinear_cb8_kernel<kLpp>,
+                           dim3((unsigned)((n_pix * kLpp + 255) / 256)), dim3(256), 0, s, c4.ptr,
+                           c4.H, c4.W, (long long)c4.frame_floats(), ex->out_h, ex->out_w,
+                           ex->batch, d_feat_out, ex->d_bneck_w, ex->bneck_scale, ex->bneck_shift,
+                           d_bottleneck_out);
+        DODT_LAUNCH_CHECK();
+        return DODT_OK;
+    }
     RUN("upconv3"); RUN("pyramid_fusion3");
     RUN("upconv2"); RUN("pyramid_fusion2");
     RUN("upconv1");
@@ -689,6 +782,14 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
                            ex->bneck_shift, d_bottleneck_out);
         DODT_LAUNCH_CHECK();
     }
+    return DODT_OK;
+}
+
+int dodt_extractor_output_shape(const dodt_extractor* ex, int* h, int* w, int* c) {
+    DODT_REQUIRE(ex, "dodt_extractor_output_shape: NULL argument");
+    if (h) *h = ex->out_h;
+    if (w) *w = ex->out_w;
+    if (c) *c = ex->out_c;
     return DODT_OK;
 }
 
@@ -742,19 +843,25 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
 double dodt_extractor_bytes(const dodt_extractor* ex) {
     if (!ex) return 0.0;
     // algorithmic HBM bytes of one forward: every layer reads its input map and its weights
-    // once and writes its output map once (pooled copies and the bottleneck included)
+    // once and writes its output map once (pooled copies and the bottleneck included); split
+    // mode keeps two bf16 maps (hi + lo) and two bf16 weight sets per tensor
     double b = 0.0;
     for (const Layer& l : ex->layers) {
-        const double in_e = ex->buf[l.src].bf16 ? 2.0 : 4.0;
-        const double out_e = ex->buf[l.dst].bf16 ? 2.0 : 4.0;
-        const double w_e = (ex->bf16 && &l != &ex->layers[0]) ? 2.0 : 4.0;
+        const Buffer& src = ex->buf[l.src];
+        const Buffer& dst = ex->buf[l.dst];
+        const double in_e = src.bf16 ? 2.0 * src.parts : 4.0;
+        const double out_e = dst.bf16 ? 2.0 * dst.parts : 4.0;
+        const double w_e = (ex->bf16 && &l != &ex->layers[0]) ? 2.0 * ex->parts : 4.0;
         const double oh = l.deconv ? 2.0 * l.H : l.H, ow = l.deconv ? 2.0 * l.W : l.W;
         b += ex->batch * ((double)l.H * l.W * l.real_cin * in_e + oh * ow * l.Cout * out_e) +
              9.0 * l.real_cin * l.Cout * w_e;
         if (l.name == "conv1_2" || l.name == "conv2_2" || l.name == "conv3_3")
-            b += ex->batch * (oh / 2) * (ow / 2) * l.Cout * out_e;
+            b += ex->batch * std::floor(oh / 2) * std::floor(ow / 2) * l.Cout * out_e;
     }
-    b += (double)ex->batch * ex->in_h * ex->in_w * 4.0;   // bottleneck map
+    if (ex->kind == DODT_EXTRACTOR_VGG)   // upsampling: conv4_3 read, the feature map written
+        b += (double)ex->batch * ((double)ex->buf[C4C].H * ex->buf[C4C].W * 256 +
+                                  (double)ex->out_h * ex->out_w * 256) * 4.0;
+    b += (double)ex->batch * ex->out_h * ex->out_w * 4.0;   // bottleneck map
     return b;
 }
 

@@ -240,7 +240,9 @@ __device__ __forceinline__ void pool_tile(const ConvArgs& a, const f32x16& v, co
     const long long plane = (long long)(a.H >> 1) * OW * 8;
     float* base = a.pool_out + (size_t)frame * a.pool_frame_stride +
                   ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
-    const bool writer = ok && !(y & 1) && !(x & 1);
+    // VALID pooling: a trailing odd row / column has no window (plain-VGG levels such as
+    // 175 x 200 -> 87 x 100)
+    const bool writer = ok && !(y & 1) && !(x & 1) && y + 1 < a.H && x + 1 < a.W;
     f32x2 half = {0.f, 0.f}, half_lo = {0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

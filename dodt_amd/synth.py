@@ -68,11 +68,15 @@ def image_frame(seq, frame, wh=IMAGE_WH):
     return rng.integers(0, 256, size=(wh[1], wh[0], 3), dtype=np.uint8)
 
 
-def pyramid_params(in_ch, seed=42):
+def pyramid_params(in_ch, seed=42, plain=False):
     """Per-layer rng(seed + layer index): w ~ N(0, 2/(9 Cin)) in TF layout
-    (HWIO; HWOI for the transposed convs), BN mean 0 / var 1 / beta ~ N(0, .01)."""
+    (HWIO; HWOI for the transposed convs), BN mean 0 / var 1 / beta ~ N(0, .01).
+    plain: the encoder-only extractors of config 1 (bev_vgg.py / img_vgg.py): conv1_1 ..
+    conv4_3 (the same draws as the pyramid's encoder) and a 256 -> 1 bottleneck."""
     params = {}
     for li, name in enumerate(PYRAMID_LAYERS):
+        if plain and not name.startswith('conv'):
+            continue
         cin, cout = PYRAMID_CHANNELS[name]
         cin = in_ch if cin is None else cin
         rng = np.random.default_rng(seed + li)
@@ -84,8 +88,9 @@ def pyramid_params(in_ch, seed=42):
             mean=np.zeros(cout, dtype=np.float32),
             var=np.ones(cout, dtype=np.float32))
     rng = np.random.default_rng(seed + 100)
+    fc = 256 if plain else 32
     params['bottleneck'] = dict(
-        w=rng.normal(0, np.sqrt(2.0 / 32), size=(1, 1, 32, 1)).astype(np.float32),
+        w=rng.normal(0, np.sqrt(2.0 / fc), size=(1, 1, fc, 1)).astype(np.float32),
         beta=rng.normal(0, 0.01, size=1).astype(np.float32),
         mean=np.zeros(1, dtype=np.float32), var=np.ones(1, dtype=np.float32))
     return params

@@ -169,6 +169,12 @@ int dodt_img_preprocess(dodt_ctx* ctx, const uint8_t* d_img_u8, int in_h, int in
  * 30-177) plus the 1x1 bottleneck (models/dt_rpn_model.py:298-322). */
 typedef struct dodt_extractor dodt_extractor;
 #define DODT_EXTRACTOR_VGG_PYR 0
+/* The plain-VGG extractors of the AVOD cars_example configuration (BASELINE.json configs[0]):
+ * BevVgg / ImgVgg.build (avod/core/feature_extractors/bev_vgg.py:34-118, img_vgg.py:33-120):
+ * the same encoder (conv1_1 .. conv4_3, three VALID 2x2 pools that floor odd sizes), then
+ * tf.image.resize_bilinear of conv4_3 to (in_h / 8 * 4, in_w / 8 * 4) -- 256 channels -- and the
+ * 256 -> 1 bottleneck of avod/core/models/rpn_model.py:251-267.  fp32 only, pad_top = 0. */
+#define DODT_EXTRACTOR_VGG 1
 /* OR into `kind`: the extractor shares the GPU with other streams (the frame-pair pipeline
  * runs both nets side by side).  Layers are then single launches: the tail launches that
  * even out a layer's last round when it has the GPU to itself only add work when another
@@ -194,7 +200,8 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
                           int pad_top, int batch, dodt_extractor** out);
 int dodt_extractor_destroy(dodt_extractor* ex);
 /* One conv layer: name as in the TF variable scope ("conv1_1" ... "conv4_3",
- * "upconv3", "pyramid_fusion3", ..., "bottleneck").  w: HWIO (kh,kw,cin,cout)
+ * "upconv3", "pyramid_fusion3", ..., "bottleneck" -- (1,1,32,1), or (1,1,256,1) for
+ * DODT_EXTRACTOR_VGG).  w: HWIO (kh,kw,cin,cout)
  * for conv2d, (kh,kw,cout,cin) for conv2d_transpose, as TF stores them.
  * beta/mean/var: slim.batch_norm variables (no gamma, eps = 1e-3).  Host memory. */
 int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* w,
@@ -205,9 +212,14 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
  * that writes there (e.g. dodt_bev_slices) can pass d_in = NULL to forward. */
 int dodt_extractor_input(dodt_extractor* ex, float** d_ptr, long long* frame_stride_floats);
 /* d_in: (batch, in_h, in_w, in_c) or NULL (see above); d_feat_out: (batch, in_h, in_w, 32);
- * d_bottleneck_out (may be NULL): (batch, in_h, in_w, 1). */
+ * d_bottleneck_out (may be NULL): (batch, in_h, in_w, 1).  DODT_EXTRACTOR_VGG: the outputs are
+ * (batch, out_h, out_w, 256) and (batch, out_h, out_w, 1), sizes from
+ * dodt_extractor_output_shape. */
 int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_out,
                            float* d_bottleneck_out);
+/* Size of the feature map forward() returns: (in_h, in_w, 32) for the pyramid,
+ * (in_h / 8 * 4, in_w / 8 * 4, 256) for DODT_EXTRACTOR_VGG. */
+int dodt_extractor_output_shape(const dodt_extractor* ex, int* h, int* w, int* c);
 /* Debug/test access to an intermediate activation by layer name: copies the
  * (batch, h, w, c) float32 tensor to host memory `dst` (NULL to query shape). */
 int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* dst,

@@ -81,13 +81,16 @@ def vgg_pyramid(x, params, pad_top=0, collect=None, conv_dtype='f32'):
     return f1[pad_top:]
 
 
-def vgg_plain(x, params, upsample=4):
-    """Config-1 extractors (bev_vgg.py / img_vgg.py): encoder, then bilinear
-    resize of conv4 to (H/8*4, W/8*4)."""
+def vgg_plain(x, params, upsample=4, collect=None):
+    """Config-1 extractors (bev_vgg.py:34-118 / img_vgg.py:33-120): encoder, then
+    tf.image.resize_bilinear of conv4_3 to input_pixel_size / 8 * upsampling_multiplier -- a
+    float pair (bev_vgg.py:102-109) that TF casts to int32: (350, 400) for the 700 x 800 BEV
+    input although conv4 is 87 x 100, (240, 795) for the 480 x 1590 image."""
     x = np.asarray(x, dtype=np.float32)
-    c4 = encoder(x, params)[3]
-    return tfops.resize_bilinear(c4, c4.shape[0] * upsample,
-                                 c4.shape[1] * upsample)
+    c4 = encoder(x, params, collect)[3]
+    out_h = int(x.shape[0] / 8 * upsample)
+    out_w = int(x.shape[1] / 8 * upsample)
+    return tfops.resize_bilinear(c4, out_h, out_w)
 
 
 def bottleneck_1x1(x, p):
