@@ -39,52 +39,117 @@ def parse():
                          "'bf16' = BASELINE configs[2]'s bf16 conv path (bf16 MFMA, fp32 accumulate)")
     ap.add_argument('--head-dtype', choices=('f32', 'bf16'), default='f32',
                     help='arithmetic of the dense heads (fp32 MFMA or bf16 MFMA, fp32 accumulate)')
+    ap.add_argument('--config', choices=('dodt', 'cars_example'), default='dodt',
+                    help="'dodt' = pyramid_cars_with_aug_dt_5_tracking frame pairs (the metric's "
+                         "workload); 'cars_example' = BASELINE.json configs[0]: single frames "
+                         'through the plain-VGG AVOD configuration (value is then frames/s)')
     ap.add_argument('--no-alt', action='store_true',
                     help='skip the short extra run with the other conv arithmetic')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-pairs', type=int, default=2,
+                    help='frame pairs (= pool workers) of the CPU baseline sample')
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, synth, budget_s, computed_heads=True):
-    """The oracle ('port' of the reference's algorithm) timed on this host: whole
-    frame pairs -- numpy point path + numpy conv stacks + crop/NMS -- until about
-    budget_s seconds have been spent.  Test infrastructure used as a yardstick,
-    never as the product."""
-    from oracle import pipeline as opipe
+def _usable_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota and by
+    the GPU box's per-GPU share of 16 (DODT_CPU_CORES overrides)."""
+    if os.environ.get('DODT_CPU_CORES'):
+        return max(1, int(os.environ['DODT_CPU_CORES']))
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        cores = os.cpu_count()
-    bev_params = synth.pyramid_params(6, 42)
-    img_params = synth.pyramid_params(3, 142)
-    head_params = synth.head_params() if computed_heads else None
-    t0 = time.perf_counter()
-    frames = 0
-    while True:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def _cpu_pair_worker(job):
+    """One whole frame pair through the oracle with `threads` BLAS threads (a pool worker)."""
+    seq, threads, computed = job
+    from threadpoolctl import threadpool_limits
+    from dodt_amd import config, synth
+    from oracle import pipeline as opipe
+    cfg = config.PYRAMID_DODT
+    with threadpool_limits(limits=threads):
+        t0 = time.perf_counter()
+        bev_params = synth.pyramid_params(6, 42)
+        img_params = synth.pyramid_params(3, 142)
         inps, feats = [], []
-        for f in (frames, frames + 2):
-            xyzi = synth.lidar_frame(9, f)
-            img = synth.image_frame(9, f)
+        for f in (0, 2):
+            xyzi = synth.lidar_frame(seq, f)
+            img = synth.image_frame(seq, f)
             inp = opipe.frame_inputs(xyzi, cfg, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
                                      synth.IMAGE_WH)
             inps.append(inp)
             feats.append(opipe.extract(inp['bev'], img, bev_params, img_params, cfg['img_dims']))
-        if computed_heads:
-            opipe.pair_detections_computed(inps, feats, head_params, cfg, synth.P2,
+        if computed:
+            opipe.pair_detections_computed(inps, feats, synth.head_params(), cfg, synth.P2,
                                            synth.IMAGE_WH, 1024)
         else:
-            for k, f in enumerate((frames, frames + 2)):
-                opipe.frame_detections(inps[k], synth.head_outputs(9, f, 89600, 1024), cfg,
+            for k, f in enumerate((0, 2)):
+                opipe.frame_detections(inps[k], synth.head_outputs(seq, f, 89600, 1024), cfg,
                                        synth.P2, synth.IMAGE_WH, 1024, *feats[k], frame_mark=k)
-        frames += 2
-        el = time.perf_counter() - t0
-        if el > budget_s or frames >= 8:
-            break
-    return dict(value=(frames / 2.0) / el, unit='frame-pairs/s', cores=int(cores), kind='port',
-                sample='%d synthetic frame pairs through oracle/pipeline.py: numpy point path + '
-                       'numpy/BLAS fp32 conv stacks + crop + NMS%s' %
-                       (frames // 2, ' + correlation + dense heads' if computed_heads else ''))
+        return time.perf_counter() - t0
+
+
+def _cpu_points_worker(job):
+    """The numpy point path a0-a6 of `n` frames on one thread (the part of the path the
+    reference itself runs on the CPU): seconds spent."""
+    seq, n = job
+    from threadpoolctl import threadpool_limits
+    from dodt_amd import config, synth
+    from oracle import pipeline as opipe
+    cfg = config.PYRAMID_DODT
+    clouds = [synth.lidar_frame(seq, f) for f in range(n)]
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        for xyzi in clouds:
+            opipe.frame_inputs(xyzi, cfg, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                               synth.IMAGE_WH)
+        return time.perf_counter() - t0
+
+
+def cpu_baseline(computed_heads=True, pairs=2):
+    """The oracle ('port' of the reference's algorithm) timed on this host's cores, before
+    anything touches the GPU (the pool's workers are fresh processes).  Test infrastructure
+    used as a yardstick, never as the product.
+      value        whole frame pairs / s: a frame-parallel pool of `pairs` workers, each one
+                   pair with cores // pairs BLAS threads (SURVEY 8d: restatement of the TF
+                   half, thread count stated)
+      point_path   the numpy half a0-a6 alone, which is how far the reference itself runs on
+                   a CPU: 1 process x 1 thread, and a pool of `cores` single-thread workers"""
+    import multiprocessing as mp
+    cores = _usable_cores()
+    workers = max(1, min(pairs, cores))
+    threads = max(1, cores // workers)
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(workers) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_pair_worker, [(20 + i, threads, computed_heads) for i in range(workers)])
+        wall = time.perf_counter() - t0
+    one = _cpu_points_worker((30, 4))
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_points_worker, [(40 + i, 1) for i in range(cores)])     # spawn + import
+        t0 = time.perf_counter()
+        pool.map(_cpu_points_worker, [(50 + i, 4) for i in range(cores)])
+        pool_wall = time.perf_counter() - t0
+    return dict(value=workers / wall, unit='frame-pairs/s', cores=int(workers * threads),
+                kind='port',
+                sample='%d synthetic frame pairs through oracle/pipeline.py (numpy point path + '
+                       'numpy/BLAS fp32 conv stacks + crop + NMS%s), frame-parallel pool of %d '
+                       'processes x %d BLAS threads, %.1f s wall'
+                       % (workers, ' + correlation + dense heads' if computed_heads else '',
+                          workers, threads, wall),
+                point_path={'stages': 'a0-a6 (points -> BEV maps, anchor filter, projections)',
+                            'one_thread_frames_per_s': round(4 / one, 3),
+                            'pool_frames_per_s': round(4 * cores / pool_wall, 3),
+                            'pool_workers': cores, 'unit': 'frames/s'})
 
 
 def main():
@@ -105,6 +170,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     n_gpus = max(args.gpus, 1)
+    baseline = None
+    if not args.no_cpu_baseline and world == 1:
+        # first, while the GPU is still untouched: the workers are spawned processes
+        baseline = cpu_baseline(args.heads == 'computed', args.cpu_pairs)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -115,32 +184,36 @@ def main():
 
     from dodt_amd import config, device, sharding, synth
     from dodt_amd.pipeline import FramePairPipeline, MAX_DET, REC_COLS
-    cfg = config.PYRAMID_DODT
+    cfg = config.PYRAMID_DODT if args.config == 'dodt' else config.CARS_EXAMPLE
     stream = torch.cuda.current_stream().cuda_stream
     ctx = device.Context(local_rank, stream=stream)
     pps = args.pairs_per_step
     computed = args.heads == 'computed'
     made = []   # pipelines built so far: later ones reuse the first one's streams
 
-    def measure(conv_dtype, steps, warmup, head_dtype='f32'):
+    def measure(conv_dtype, steps, warmup, head_dtype='f32', cfg=cfg, proposals=args.proposals,
+                from_host=False):
         """`steps` timed steps of the pipeline built for conv_dtype, then the conv stacks
         alone (roofline).  Returns a dict of raw measurements."""
-        pipe = FramePairPipeline(ctx, cfg, n_points_max=args.points, rpn_nms_size=args.proposals,
+        fps = cfg['frames_per_sample']
+        feat_c = 256 if cfg['extractor'] == 'vgg' else 32
+        pipe = FramePairPipeline(ctx, cfg, **synth.pipeline_weights(cfg),
+                                 n_points_max=args.points, rpn_nms_size=proposals,
                                  pairs_per_step=pps,
-                                 head_params=synth.head_params() if computed else None,
+                                 head_params=synth.head_params(feat=feat_c) if computed else None,
                                  conv_dtype=conv_dtype, head_dtype=head_dtype,
-                                 reuse_streams_of=made[0] if made else None)
+                                 reuse_streams_of=made[0] if made and made[0].fps == fps else None)
         made.append(pipe)
 
         # detection records live in torch memory so that RCCL can ship them
         # (two of each: the pipeline alternates them by step parity)
-        rec = [torch.zeros((pps, 2, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
+        rec = [torch.zeros((pps, fps, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
                for _ in range(2)]
-        cnt = [torch.zeros((pps, 2), dtype=torch.int32, device='cuda') for _ in range(2)]
+        cnt = [torch.zeros((pps, fps), dtype=torch.int32, device='cuda') for _ in range(2)]
         pipe.use_record_buffers([t.data_ptr() for t in rec], [t.data_ptr() for t in cnt])
-        gathered = torch.zeros((world * pps, 2, MAX_DET, REC_COLS), dtype=torch.float32,
+        gathered = torch.zeros((world * pps, fps, MAX_DET, REC_COLS), dtype=torch.float32,
                                device='cuda')
-        gathered_cnt = torch.zeros((world * pps, 2), dtype=torch.int32, device='cuda')
+        gathered_cnt = torch.zeros((world * pps, fps), dtype=torch.int32, device='cuda')
 
         # a small ring of distinct synthetic batches, resident in HBM before timing starts;
         # every pair of a batch comes from a different sequence (they are independent)
@@ -150,14 +223,24 @@ def main():
             pts, imgs, heads = [], [], []
             for j in range(pps):
                 seq = (rank * n_batches + i) * pps + j
-                for f in (2 * i, 2 * i + 2):                             # tau = 2
+                for f in ((2 * i, 2 * i + 2) if fps == 2 else (2 * i,)):      # tau = 2
                     pts.append(synth.lidar_frame(seq, f, args.points))
                     imgs.append(ctx.array(synth.image_frame(seq, f)))
                     if not computed:
                         heads.append({k: ctx.array(v) for k, v in
                                       synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()})
-            batches.append(dict(pts=[ctx.array(p) for p in pts], n=[len(p) for p in pts],
-                                imgs=imgs, heads=None if computed else heads))
+            b = dict(pts=[ctx.array(p) for p in pts], n=[len(p) for p in pts],
+                     imgs=imgs, heads=None if computed else heads)
+            if from_host:   # the same frames in page-locked host memory (PCIe-inclusive run)
+                b['h_pts'], b['h_imgs'] = [], []
+                for p_, d_img in zip(pts, imgs):
+                    hp = ctx.pinned((args.points, 4), np.float32)
+                    hp.a[:len(p_)] = p_
+                    hi = ctx.pinned(d_img.shape, np.uint8)
+                    hi.a[...] = d_img.download()
+                    b['h_pts'].append(hp)
+                    b['h_imgs'].append(hi)
+            batches.append(b)
 
         state = {'n': 0, 'par': 0}
 
@@ -177,7 +260,10 @@ def main():
 
         def step(i):
             p = batches[i % n_batches]
-            par = pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
+            if from_host:
+                par = pipe.run_from_host(p['h_pts'], p['n'], p['h_imgs'], p['heads'])
+            else:
+                par = pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
             if state['n'] > 0:     # records of the previous step are complete on this stream
                 gather(1 - par)
             state['n'] += 1
@@ -271,8 +357,8 @@ def main():
         # measurement, never part of `value`
         k = max(5, args.steps // 2)
 
-        def short(conv_dtype, head_dtype):
-            a = measure(conv_dtype, k, 2, head_dtype)
+        def short(conv_dtype, head_dtype, **kw):
+            a = measure(conv_dtype, k, 2, head_dtype, **kw)
             return {'conv_dtype': conv_dtype, 'head_dtype': head_dtype,
                     'value': round(world * k * pps / a['elapsed'], 3), 'unit': 'frame-pairs/s',
                     'steps': k, 'ms_per_step': round(a['elapsed'] / k * 1e3, 4),
@@ -286,6 +372,21 @@ def main():
                'runs': [short(c, h) for c, h in (('f32', 'f32'), ('f32s', 'f32'), ('bf16', 'f32'),
                                                   ('bf16', 'bf16'))
                         if (c, h) != (args.conv_dtype, args.head_dtype) and (computed or h == 'f32')]}
+        if args.config == 'dodt':
+            # BASELINE.json configs[0]: single frames through the AVOD cars_example
+            # configuration (plain VGG extractors, 480 x 1590 image, 300 proposals, fp32)
+            r = short('f32', 'f32', cfg=config.CARS_EXAMPLE,
+                      proposals=config.CARS_EXAMPLE['rpn_test_nms_size'])
+            r.update(unit='frames/s', config='avod_cars_example: bev_vgg + img_vgg, 1 frame '
+                                             'per step (BASELINE.json configs[0])')
+            alt['cars_example'] = r
+            # PCIe-inclusive: raw frames start in page-locked host memory and are copied by
+            # hipMemcpyAsync on the prep streams inside every step (never `value`)
+            r = short(args.conv_dtype, args.head_dtype, from_host=True)
+            r['inputs'] = ('2 x (%d x 16 B points + 1242x375x3 B image) = %.1f MB per pair from '
+                           'pinned host memory inside each step'
+                           % (args.points, 2 * (args.points * 16 + 1242 * 375 * 3) / 1e6))
+            alt['pcie_inclusive'] = r
     flops = m['flops']
     achieved = flops / (conv_ms * 1e-3) / 1e12
     # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
@@ -347,11 +448,15 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_dtype, 'data': 'synthetic',
             'head_dtype': args.head_dtype,
-            'config': {'workload': 'DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
-                                   'pyramid_cars_with_aug_dt_5_tracking, %d proposals, '
-                                   '%s' % (args.points // 1000, args.proposals,
-                                           'S+T path: correlation + dense heads on the device'
-                                           if computed else 'S path (heads injected)'),
+            'config': {'workload': ('DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
+                                    'pyramid_cars_with_aug_dt_5_tracking (box_4ca), %d proposals, '
+                                    '%s' % (args.points // 1000, args.proposals,
+                                            'S+T path: correlation + dense heads on the device'
+                                            if computed else 'S path (heads injected)'))
+                       if args.config == 'dodt' else
+                       ('AVOD single frame: %dk pts + 1242x375 RGB, avod_cars_example (plain '
+                        'VGG extractors, box_4ca), %d proposals; value counts FRAMES/s'
+                        % (args.points // 1000, args.proposals)),
                        'head_gflop_per_step': round(m['head_gflop'], 2),
                        'pairs_per_step_per_gpu': pps, 'parallelism': 'pair-shard x%d' % world,
                        'anchors_kept': m['anchors']},
@@ -359,8 +464,8 @@ def main():
         }
         if alt is not None:
             out['alt'] = alt
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(cfg, synth, args.cpu_seconds, computed)
+        if baseline is not None:
+            out['cpu_baseline'] = baseline
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -69,6 +69,9 @@ SIGNATURES = {
     'dodt_memcpy_h2d': (_i, [_vp, _vp, _vp, C.c_size_t]),
     'dodt_memcpy_d2h': (_i, [_vp, _vp, _vp, C.c_size_t]),
     'dodt_memset': (_i, [_vp, _vp, _i, C.c_size_t]),
+    'dodt_pinned_alloc': (_i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    'dodt_pinned_free': (_i, [_vp, _vp]),
+    'dodt_memcpy_h2d_async': (_i, [_vp, _vp, _vp, C.c_size_t]),
     'dodt_fetch_i32_begin': (_i, [_vp, _pi32, _i, _i]),
     'dodt_fetch_i32_end': (_i, [_vp, _i, C.POINTER(C.c_int32), _i]),
     'dodt_timer_start': (_i, [_vp]),

@@ -47,14 +47,45 @@ _COMMON = dict(
     box_representation='box_4ca',
 )
 
+# frames_per_sample: 2 = DODT's Siamese model over a (t, t + tau) frame pair with the
+# correlation branch (dt_rpn_model.py / dt_avod_model.py); 1 = single-frame AVOD
+# (rpn_model.py / avod_model.py).  feat_stride / feat_depth: the extractor's output map
+# relative to its input (pyramid: full resolution x 32; plain VGG: H/8*4 x 256).
 PYRAMID_DODT = dict(_COMMON,
                     name='pyramid_cars_with_aug_dt_5_tracking',
+                    model='dt_avod_model',
+                    frames_per_sample=2,
                     extractor='vgg_pyr',
                     img_dims=(360, 1200),
                     img_depth=3)
 
 CARS_EXAMPLE = dict(_COMMON,
                     name='avod_cars_example',
+                    model='avod_model',
+                    frames_per_sample=1,
                     extractor='vgg',
                     img_dims=(480, 1590),
                     img_depth=3)
+
+# Calibration of the tracking sequence the reference's tests bundle
+# (avod/tests/datasets/Kitti/tracking/training/calib/0000.txt, numbers only) and the KITTI
+# image size: the default camera of the synthetic benchmarks and parity tests.
+KITTI_P2 = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01],
+                     [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01],
+                     [0.0, 0.0, 1.0, 2.745884e-03]])
+KITTI_R0_RECT = np.array([[9.999239e-01, 9.837760e-03, -7.445048e-03],
+                          [-9.869795e-03, 9.999421e-01, -4.278459e-03],
+                          [7.402527e-03, 4.351614e-03, 9.999631e-01]])
+KITTI_TR_VELO_TO_CAM = np.array(
+    [[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
+     [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
+     [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01]])
+KITTI_IMAGE_WH = (1242, 375)
+
+
+def velo_to_cam(r0_rect=KITTI_R0_RECT, tr=KITTI_TR_VELO_TO_CAM):
+    """(3,4) = (R0_rect padded . Tr_velo_to_cam padded)[0:3], float64
+    (wavedata/.../calib_utils.py:502-519)."""
+    r0 = np.zeros((4, 4)); r0[:3, :3] = r0_rect; r0[3, 3] = 1
+    t = np.zeros((4, 4)); t[:3, :4] = tr; t[3, 3] = 1
+    return np.dot(r0, t)[:3]

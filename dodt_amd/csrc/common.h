@@ -62,6 +62,8 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 }  // namespace dodt
 
+constexpr int kFetchSlots = 32;   // dodt_fetch_i32_* slots per context
+
 struct dodt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -71,8 +73,8 @@ struct dodt_ctx {
     dodt::Scratch anchor_ws; // anchor filter: mask + block counts
     dodt::Scratch nms_ws;    // NMS: keys, sorted boxes, suppression mask
     int num_cus = 256;
-    int32_t* pinned = nullptr;       // 8 slots x 16 int32, hipHostMalloc
-    hipEvent_t fetch_ev[8] = {};
+    int32_t* pinned = nullptr;       // kFetchSlots x 16 int32, hipHostMalloc
+    hipEvent_t fetch_ev[kFetchSlots] = {};
     hipEvent_t mark_ev[16] = {};     // timing marks for tools/ (created on first use)
     hipEvent_t join_ev = nullptr;    // recorded on this stream for dodt_ctx_wait_for
 };

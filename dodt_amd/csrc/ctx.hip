@@ -75,8 +75,8 @@ static int ctx_create(int device_id, hipStream_t stream, bool external, bool hig
     }
     (void)hipEventCreate(&c->ev_start);
     (void)hipEventCreate(&c->ev_stop);
-    (void)hipHostMalloc(reinterpret_cast<void**>(&c->pinned), 8 * 16 * sizeof(int32_t), 0);
-    for (int i = 0; i < 8; ++i) (void)hipEventCreateWithFlags(&c->fetch_ev[i], hipEventDisableTiming);
+    (void)hipHostMalloc(reinterpret_cast<void**>(&c->pinned), kFetchSlots * 16 * sizeof(int32_t), 0);
+    for (int i = 0; i < kFetchSlots; ++i) (void)hipEventCreateWithFlags(&c->fetch_ev[i], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming);
     *out = c;
     return DODT_OK;
@@ -102,7 +102,7 @@ int dodt_ctx_destroy(dodt_ctx* ctx) {
     ctx->anchor_ws.release();
     ctx->nms_ws.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < kFetchSlots; ++i)
         if (ctx->fetch_ev[i]) (void)hipEventDestroy(ctx->fetch_ev[i]);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     for (int i = 0; i < 16; ++i)
@@ -174,6 +174,26 @@ int dodt_memcpy_d2h(dodt_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
     return DODT_OK;
 }
 
+int dodt_pinned_alloc(dodt_ctx* ctx, size_t bytes, void** out) {
+    DODT_REQUIRE(ctx && out, "dodt_pinned_alloc: NULL argument");
+    DODT_HIP_CHECK(hipSetDevice(ctx->device));
+    DODT_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 1, 0));
+    return DODT_OK;
+}
+
+int dodt_pinned_free(dodt_ctx* ctx, void* ptr) {
+    DODT_REQUIRE(ctx, "dodt_pinned_free: ctx is NULL");
+    if (ptr) DODT_HIP_CHECK(hipHostFree(ptr));
+    return DODT_OK;
+}
+
+int dodt_memcpy_h2d_async(dodt_ctx* ctx, void* d_dst, const void* pinned_src, size_t bytes) {
+    DODT_REQUIRE(ctx && (bytes == 0 || (d_dst && pinned_src)), "dodt_memcpy_h2d_async: NULL argument");
+    if (bytes == 0) return DODT_OK;
+    DODT_HIP_CHECK(hipMemcpyAsync(d_dst, pinned_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return DODT_OK;
+}
+
 int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes) {
     DODT_REQUIRE(ctx && (bytes == 0 || d_dst), "dodt_memset: NULL argument");
     if (bytes == 0) return DODT_OK;
@@ -183,7 +203,7 @@ int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes) {
 
 int dodt_fetch_i32_begin(dodt_ctx* ctx, const int32_t* d_src, int n, int slot) {
     DODT_REQUIRE(ctx && d_src && ctx->pinned, "dodt_fetch_i32_begin: NULL argument");
-    DODT_REQUIRE(n >= 1 && n <= 16 && slot >= 0 && slot < 8, "dodt_fetch_i32_begin: bad n/slot");
+    DODT_REQUIRE(n >= 1 && n <= 16 && slot >= 0 && slot < kFetchSlots, "dodt_fetch_i32_begin: bad n/slot");
     DODT_HIP_CHECK(hipMemcpyAsync(ctx->pinned + slot * 16, d_src, n * sizeof(int32_t),
                                   hipMemcpyDeviceToHost, ctx->stream));
     DODT_HIP_CHECK(hipEventRecord(ctx->fetch_ev[slot], ctx->stream));
@@ -192,7 +212,7 @@ int dodt_fetch_i32_begin(dodt_ctx* ctx, const int32_t* d_src, int n, int slot) {
 
 int dodt_fetch_i32_end(dodt_ctx* ctx, int slot, int32_t* dst, int n) {
     DODT_REQUIRE(ctx && dst && ctx->pinned, "dodt_fetch_i32_end: NULL argument");
-    DODT_REQUIRE(n >= 1 && n <= 16 && slot >= 0 && slot < 8, "dodt_fetch_i32_end: bad n/slot");
+    DODT_REQUIRE(n >= 1 && n <= 16 && slot >= 0 && slot < kFetchSlots, "dodt_fetch_i32_end: bad n/slot");
     DODT_HIP_CHECK(hipEventSynchronize(ctx->fetch_ev[slot]));
     for (int i = 0; i < n; ++i) dst[i] = ctx->pinned[slot * 16 + i];
     return DODT_OK;

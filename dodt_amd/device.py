@@ -37,6 +37,15 @@ class DeviceArray(object):
             self.ctx.handle, self.ptr, a.ctypes.data, a.nbytes), 'h2d')
         return self
 
+    def upload_async(self, pinned, ctx=None, nbytes=None):
+        """Enqueue a copy from a PinnedArray on ctx's stream; the host does not wait."""
+        c = ctx or self.ctx
+        n = pinned.nbytes if nbytes is None else int(nbytes)
+        if n > self.nbytes or n > pinned.nbytes:
+            raise ValueError('upload_async: %d bytes do not fit' % n)
+        _lib.check(c.lib.dodt_memcpy_h2d_async(c.handle, self.ptr, pinned.ptr, n), 'h2d async')
+        return self
+
     def download(self):
         out = np.empty(self.shape, dtype=self.dtype)
         _lib.check(self.ctx.lib.dodt_memcpy_d2h(
@@ -58,6 +67,30 @@ class DeviceArray(object):
             self.free()
         except Exception:
             pass
+
+
+class PinnedArray(object):
+    """Page-locked host memory viewed as a numpy array (`.a`); the source of copies that do
+    not block the host (DeviceArray.upload_async)."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.check(ctx.lib.dodt_pinned_alloc(ctx.handle, self.nbytes, C.byref(p)),
+                   'dodt_pinned_alloc')
+        self.ptr = p.value
+        buf = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+        self.a = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(
+            self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.a = None
+            self.ctx.lib.dodt_pinned_free(self.ctx.handle, self.ptr)
+            self.ptr = None
 
 
 class Context(object):
@@ -87,6 +120,9 @@ class Context(object):
     def array(self, host, dtype=None):
         host = np.asarray(host)
         return DeviceArray(self, host.shape, dtype or host.dtype).upload(host)
+
+    def pinned(self, shape, dtype=np.float32):
+        return PinnedArray(self, shape, dtype)
 
     def wrap(self, ptr, shape, dtype=np.float32):
         return DeviceArray(self, shape, dtype, ptr=int(ptr))

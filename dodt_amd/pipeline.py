@@ -27,11 +27,16 @@ import os
 
 import numpy as np
 
-from dodt_amd import device, ops, synth
+from dodt_amd import config as _config
+from dodt_amd import device, ops
 from dodt_amd.core.anchor_generators import grid_anchor_3d_generator as gen
 from dodt_amd.core.avod_fc_layers.fusion_fc_layers import EarlyFusionFcLayers
+from dodt_amd.core.feature_extractors.vgg import BevVgg, ImgVgg
 from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr, ImgVggPyr
 from dodt_amd.core.models.anchor_predictor import AnchorPredictor
+
+# feature_extractor_builder.get_extractor (avod/builders/feature_extractor_builder.py:8-24)
+EXTRACTORS = {'vgg_pyr': (BevVggPyr, ImgVggPyr), 'vgg': (BevVgg, ImgVgg)}
 
 MAX_DET = 100            # avod_nms_size
 REC_COLS = 17            # dt_evaluator.py:1217-1257
@@ -41,9 +46,16 @@ CORR_CH = (2 * (CORR_MAX_DISP // CORR_STRIDE2) + 1) ** 2
 
 
 class FramePairPipeline(object):
-    def __init__(self, ctx, cfg, p2=synth.P2, r0_rect=synth.R0_RECT,
-                 tr_velo_to_cam=synth.TR_VELO_TO_CAM, image_wh=synth.IMAGE_WH,
-                 n_points_max=120000, rpn_nms_size=1024, bev_params=None, img_params=None,
+    """One GPU's pipeline over samples of the configuration: frame pairs for DODT
+    (cfg['frames_per_sample'] == 2: Siamese extractors + correlation branch,
+    dt_rpn_model.py / dt_avod_model.py) or single frames for plain AVOD
+    (frames_per_sample == 1, e.g. config.CARS_EXAMPLE: rpn_model.py / avod_model.py, no
+    correlation branch; `pairs_per_step` then counts frames).  The extractor pair follows
+    cfg['extractor'] ('vgg_pyr' or 'vgg')."""
+
+    def __init__(self, ctx, cfg, bev_params, img_params, p2=_config.KITTI_P2,
+                 r0_rect=_config.KITTI_R0_RECT, tr_velo_to_cam=_config.KITTI_TR_VELO_TO_CAM,
+                 image_wh=_config.KITTI_IMAGE_WH, n_points_max=120000, rpn_nms_size=1024,
                  pairs_per_step=1, side_streams=None, head_params=None, conv_dtype='f32',
                  head_dtype='f32', reuse_streams_of=None):
         self.ctx = ctx
@@ -51,13 +63,17 @@ class FramePairPipeline(object):
         self.p2 = np.asarray(p2, dtype=np.float64)
         self.image_wh = tuple(image_wh)
         self.P = int(rpn_nms_size)
-        self.pairs = int(pairs_per_step)
-        self.nf = 2 * self.pairs                       # frames per step
+        self.n_points_max = int(n_points_max)
+        self.pairs = int(pairs_per_step)               # samples per step
+        self.fps = int(cfg.get('frames_per_sample', 2))
+        if self.fps not in (1, 2):
+            raise ValueError('frames_per_sample must be 1 or 2')
+        self.nf = self.fps * self.pairs                # frames per step
         self.bev_h, self.bev_w = cfg['bev_dims']
         self.img_h, self.img_w = cfg['img_dims']
         self.n_slices = cfg['num_slices']
         self.bev_extents_flat = np.asarray(cfg['bev_extents'], np.float64).reshape(-1)
-        self.bp = ops.make_bev_params(cfg, synth.velo_to_cam(r0_rect, tr_velo_to_cam),
+        self.bp = ops.make_bev_params(cfg, _config.velo_to_cam(r0_rect, tr_velo_to_cam),
                                       self.p2, self.image_wh)
         # streams: conv stacks of the two nets side by side, per-frame work on its own.
         # A second pipeline in the same process takes the first one's streams
@@ -79,12 +95,19 @@ class FramePairPipeline(object):
         self.d_cells = ctx.array(cells)
 
         # ---- extractors: every frame of the step is one batch ------------------------
-        self.bev_net = BevVggPyr(ctx=ctx, shared_gpu=True, conv_dtype=conv_dtype)
-        self.bev_net.load_params(bev_params or synth.pyramid_params(cfg['bev_depth'], 42))
+        bev_cls, img_cls = EXTRACTORS[cfg.get('extractor', 'vgg_pyr')]
+        self.bev_net = bev_cls(ctx=ctx, shared_gpu=True, conv_dtype=conv_dtype)
+        self.bev_net.load_params(bev_params)
         self.bev_net._ensure(self.nf, self.bev_h, self.bev_w, cfg['bev_depth'])
-        self.img_net = ImgVggPyr(ctx=self.img_ctx, shared_gpu=True, conv_dtype=conv_dtype)
-        self.img_net.load_params(img_params or synth.pyramid_params(cfg['img_depth'], 142))
+        self.img_net = img_cls(ctx=self.img_ctx, shared_gpu=True, conv_dtype=conv_dtype)
+        self.img_net.load_params(img_params)
         self.img_net._ensure(self.nf, self.img_h, self.img_w, 4)
+        # feature maps the crops read: (700,800,32) / (360,1200,32) for the pyramid,
+        # (350,400,256) / (240,795,256) for the plain VGG
+        self.bev_fh, self.bev_fw, self.feat_c = self.bev_net.output_shape()
+        self.img_fh, self.img_fw, img_c = self.img_net.output_shape()
+        if img_c != self.feat_c:
+            raise ValueError('mean fusion needs equal feature depths')
         # conv inputs, double-buffered so that step k+1 is prepared under the convs of step k
         self.in_bev = [ctx.empty((self.nf, self.bev_h, self.bev_w, cfg['bev_depth']), np.float32)
                        for _ in range(2)]
@@ -105,19 +128,22 @@ class FramePairPipeline(object):
             self.avod_head = EarlyFusionFcLayers(
                 ctx, head_params['avod'], dtype=head_dtype,
                 outputs=('cls_out', 'off_out') + (('ang_out',) if self.box_4ca else ()))
-            self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'], outputs=('off_out',),
-                                                 dtype=head_dtype)
+            if self.fps == 2:
+                self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'],
+                                                     outputs=('off_out',), dtype=head_dtype)
             self.head_scratch = [dict(rpn=self.rpn_head.make_scratch(N),
                                       fc=self.avod_head.make_scratch(P),
-                                      corr_map=ctx.empty((self.bev_h, self.bev_w, CORR_CH), f32))
+                                      corr_map=ctx.empty((self.bev_fh, self.bev_fw, CORR_CH), f32)
+                                      if self.fps == 2 else None)
                                  for _ in self.sides]
 
         # ---- work buffers ----------------------------------------------------------------
+        FC = self.feat_c
         self.feat = [dict(
-            bev_feat=ctx.empty((self.nf, self.bev_h, self.bev_w, 32), f32),
-            bev_bneck=ctx.empty((self.nf, self.bev_h, self.bev_w, 1), f32),
-            img_feat=ctx.empty((self.nf, self.img_h, self.img_w, 32), f32),
-            img_bneck=ctx.empty((self.nf, self.img_h, self.img_w, 1), f32)) for _ in range(2)]
+            bev_feat=ctx.empty((self.nf, self.bev_fh, self.bev_fw, FC), f32),
+            bev_bneck=ctx.empty((self.nf, self.bev_fh, self.bev_fw, 1), f32),
+            img_feat=ctx.empty((self.nf, self.img_fh, self.img_fw, FC), f32),
+            img_bneck=ctx.empty((self.nf, self.img_fh, self.img_fw, 1), f32)) for _ in range(2)]
         self.fr2 = [[], []]
         for f in range(2 * self.nf):
             b = dict(
@@ -131,7 +157,8 @@ class FramePairPipeline(object):
                 top_idx=ctx.empty((P,), i32), top_count=ctx.zeros((1,), i32),
                 top_anchors=ctx.empty((P, 6), f32),
                 top_bev=ctx.empty((P, 4), f32), top_img=ctx.empty((P, 4), f32),
-                bev_rois=ctx.empty((P, 7, 7, 32), f32), img_rois=ctx.empty((P, 7, 7, 32), f32),
+                bev_rois=ctx.empty((P, ROI, ROI, FC), f32),
+                img_rois=ctx.empty((P, ROI, ROI, FC), f32),
                 boxes_3d=ctx.empty((P, 7), f32), pred_anchors=ctx.empty((P, 6), f32),
                 nms2_boxes=ctx.empty((P, 4), f32), nms2_scores=ctx.empty((P,), f32),
                 det_idx=ctx.empty((MAX_DET,), i32), det_count=ctx.zeros((1,), i32),
@@ -141,7 +168,7 @@ class FramePairPipeline(object):
                          cls_logits=ctx.empty((P, 2), f32), offsets_4c=ctx.empty((P, 10), f32))
                 if self.box_4ca:
                     b.update(angle_vectors=ctx.empty((P, 2), f32))
-                if f % 2 == 0:
+                if self.fps == 2 and f % 2 == 0:
                     b.update(corr_rois=ctx.empty((P, ROI, ROI, CORR_CH), f32),
                              corr_offsets=ctx.empty((P, 3), f32))
             self.fr2[f // self.nf].append(b)
@@ -149,8 +176,8 @@ class FramePairPipeline(object):
         self.step_idx = 0
         self.pending = None            # step whose tail has not been enqueued yet
         # detection records of a step: what the all-gather ships; by step parity
-        self.rec2 = [ctx.empty((self.pairs, 2, MAX_DET, REC_COLS), f32) for _ in range(2)]
-        self.cnt2 = [ctx.zeros((self.pairs, 2), i32) for _ in range(2)]
+        self.rec2 = [ctx.empty((self.pairs, self.fps, MAX_DET, REC_COLS), f32) for _ in range(2)]
+        self.cnt2 = [ctx.zeros((self.pairs, self.fps), i32) for _ in range(2)]
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]   # last finished step
         self.last_anchor_counts = [0] * self.nf
         self.mark_steps = ()           # tools/pipe_marks.py: steps whose stages get timing marks
@@ -191,12 +218,38 @@ class FramePairPipeline(object):
     def use_record_buffers(self, rec_ptrs, cnt_ptrs):
         """Write detection records into caller-owned device memory (e.g. the torch tensors
         handed to torch.distributed.all_gather): two of each, used by step parity."""
-        self.rec2 = [self.ctx.wrap(p, (self.pairs, 2, MAX_DET, REC_COLS), np.float32)
+        self.rec2 = [self.ctx.wrap(p, (self.pairs, self.fps, MAX_DET, REC_COLS), np.float32)
                      for p in rec_ptrs]
-        self.cnt2 = [self.ctx.wrap(p, (self.pairs, 2), np.int32) for p in cnt_ptrs]
+        self.cnt2 = [self.ctx.wrap(p, (self.pairs, self.fps), np.int32) for p in cnt_ptrs]
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]
 
     # ------------------------------------------------------------------------------------
+    def run_from_host(self, h_points, n_points, h_images, heads=None):
+        """run() for raw frames still in (page-locked) host memory: lists of PinnedArray --
+        points (n_max,4) float32 of which n_points[f] rows are valid, images (H,W,3) uint8.
+        The copies are enqueued on each frame's prep stream in front of its prep kernels, so
+        they travel under the kernels of the previous step; the host does not wait for them
+        (the caller keeps the pinned buffers untouched until that step's prep has run, e.g.
+        by alternating two sets)."""
+        cur = self.step_idx & 1
+        ns = len(self.sides)
+        if not hasattr(self, 'stage'):
+            H, W = self.image_wh[1], self.image_wh[0]
+            self.stage = [[(self.ctx.empty((self.n_points_max, 4), np.float32),
+                            self.ctx.empty((H, W, 3), np.uint8)) for _ in range(self.nf)]
+                          for _ in range(2)]
+        d_pts, d_imgs = [], []
+        for f in range(self.nf):
+            c = self.preps[f % ns]
+            dp, di = self.stage[cur][f]
+            if n_points[f] > self.n_points_max:
+                raise ValueError('frame %d has more than n_points_max points' % f)
+            dp.upload_async(h_points[f], ctx=c, nbytes=16 * int(n_points[f]))
+            di.upload_async(h_images[f], ctx=c)
+            d_pts.append(dp)
+            d_imgs.append(di)
+        return self.run(d_pts, n_points, d_imgs, heads)
+
     def run(self, d_points, n_points, d_images, heads=None):
         """Enqueue one step.  Lists of length 2 * pairs_per_step, frame order
         [pair0 f0, pair0 f1, pair1 f0, ...]: d_points[f] (n,4) float32 velodyne xyzi;
@@ -211,7 +264,7 @@ class FramePairPipeline(object):
         main, nf = self.ctx, self.nf
         if (heads is None) != (self.rpn_head is not None):
             raise ValueError('pass `heads` exactly when the pipeline has no head_params')
-        mean = (ImgVggPyr._R_MEAN, ImgVggPyr._G_MEAN, ImgVggPyr._B_MEAN)
+        mean = (self.img_net._R_MEAN, self.img_net._G_MEAN, self.img_net._B_MEAN)
         ns = len(self.sides)
         cur = self.step_idx & 1
         fr, feat = self.fr2[cur], self.feat[cur]
@@ -227,7 +280,7 @@ class FramePairPipeline(object):
             ops.bev_slices(c, d_points[f], n_points[f], self.bp, bev_in[f], b['occ'])
             ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
                               b['keep'], b['count'])
-            ops.fetch_i32_begin(c, b['count'], 1, 2 * (f // ns) + cur)
+            ops.fetch_i32_begin(c, b['count'], 1, 2 * f + cur)
             ops.project_anchors_f64(c, self.d_anchor_table, b['keep'], self.n_all, b['count'],
                                     self.bev_extents_flat, self.p2, self.image_wh,
                                     b['bev_norm'], b['img_norm'], b['anchors'])
@@ -275,15 +328,17 @@ class FramePairPipeline(object):
         fr, feat = self.fr2[cur], self.feat[cur]
         heads = st['heads']
         # kept-anchor counts of that step: fetched by its prep streams, long complete
-        counts = [ops.fetch_i32_end(self.preps[f % ns], 2 * (f // ns) + cur, 1)[0]
+        counts = [ops.fetch_i32_end(self.preps[f % ns], 2 * f + cur, 1)[0]
                   for f in range(nf)]
         self.last_anchor_counts = counts
         self.fr = fr
         self.d_records, self.d_rec_counts = self.rec2[cur], self.cnt2[cur]
         self.d_bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w,
                                                        self.cfg['bev_depth']))
-        bev_px = self.bev_h * self.bev_w
-        img_px = self.img_h * self.img_w
+        bev_px = self.bev_fh * self.bev_fw
+        img_px = self.img_fh * self.img_fw
+        FC = self.feat_c
+        bev_hw, img_hw = (self.bev_fh, self.bev_fw), (self.img_fh, self.img_fw)
         plane = cfg['ground_plane']
         for f in range(nf):
             c, b, A = self.sides[f % ns], fr[f], counts[f]
@@ -291,14 +346,14 @@ class FramePairPipeline(object):
             h = b if computed else heads[f]
             scratch = self.head_scratch[f % ns] if computed else None
             self._mark(c, st['step'], 'tail%d_start' % f)
-            bneck_b = feat['bev_bneck'].offset(4 * bev_px * f, (self.bev_h, self.bev_w, 1))
-            bneck_i = feat['img_bneck'].offset(4 * img_px * f, (self.img_h, self.img_w, 1))
-            feat_b = feat['bev_feat'].offset(4 * bev_px * 32 * f, (self.bev_h, self.bev_w, 32))
-            feat_i = feat['img_feat'].offset(4 * img_px * 32 * f, (self.img_h, self.img_w, 32))
+            bneck_b = feat['bev_bneck'].offset(4 * bev_px * f, bev_hw + (1,))
+            bneck_i = feat['img_bneck'].offset(4 * img_px * f, img_hw + (1,))
+            feat_b = feat['bev_feat'].offset(4 * bev_px * FC * f, bev_hw + (FC,))
+            feat_i = feat['img_feat'].offset(4 * img_px * FC * f, img_hw + (FC,))
             # -- a11: RPN crops (3x3 on the 1-channel bottlenecks) ------------------------
-            ops.crop_and_resize(c, bneck_b, (self.bev_h, self.bev_w, 1), b['bev_norm'], A, None,
+            ops.crop_and_resize(c, bneck_b, bev_hw + (1,), b['bev_norm'], A, None,
                                 (3, 3), b['rpn_bev_roi'])
-            ops.crop_and_resize(c, bneck_i, (self.img_h, self.img_w, 1), b['img_norm'], A, None,
+            ops.crop_and_resize(c, bneck_i, img_hw + (1,), b['img_norm'], A, None,
                                 (3, 3), b['rpn_img_roi'])
             self._mark(c, st['step'], 'tail%d_crops' % f)
             if computed:
@@ -319,11 +374,12 @@ class FramePairPipeline(object):
             ops.project_anchors_f32(c, b['top_anchors'], self.P, b['top_count'],
                                     self.bev_extents_flat, self.p2, self.image_wh,
                                     d_bev_norm_tf=b['top_bev'], d_img_norm_tf=b['top_img'])
-            ops.crop_and_resize(c, feat_b, (self.bev_h, self.bev_w, 32), b['top_bev'], self.P,
-                                b['top_count'], (7, 7), b['bev_rois'])
-            ops.crop_and_resize(c, feat_i, (self.img_h, self.img_w, 32), b['top_img'], self.P,
-                                b['top_count'], (7, 7), b['img_rois'])
-            corr_offsets = h.get('corr_offsets') if f % 2 == 0 else None
+            ops.crop_and_resize(c, feat_b, bev_hw + (FC,), b['top_bev'], self.P,
+                                b['top_count'], (ROI, ROI), b['bev_rois'])
+            ops.crop_and_resize(c, feat_i, img_hw + (FC,), b['top_img'], self.P,
+                                b['top_count'], (ROI, ROI), b['img_rois'])
+            pair = self.fps == 2
+            corr_offsets = h.get('corr_offsets') if pair and f % 2 == 0 else None
             self._mark(c, st['step'], 'tail%d_crops2' % f)
             if computed:
                 self.avod_head.forward(c, b['bev_rois'], b['img_rois'], self.P, b['top_count'],
@@ -331,14 +387,13 @@ class FramePairPipeline(object):
                                        + ([b['angle_vectors']] if self.box_4ca else []),
                                        scratch['fc'])
                 self._mark(c, st['step'], 'tail%d_fc2' % f)
-                if f % 2 == 0 and not os.environ.get('DODT_PIPE_NO_CORR'):
+                if pair and f % 2 == 0 and not os.environ.get('DODT_PIPE_NO_CORR'):
                     # T branch: correlate the pair's BEV features, crop with frame 0's
                     # proposals (dt_rpn_model.py:324-331, dt_avod_model.py:267-273,300-304)
-                    feat_b1 = feat['bev_feat'].offset(4 * bev_px * 32 * (f + 1),
-                                                      (self.bev_h, self.bev_w, 32))
-                    ops.correlation(c, feat_b, feat_b1, (self.bev_h, self.bev_w, 32),
+                    feat_b1 = feat['bev_feat'].offset(4 * bev_px * FC * (f + 1), bev_hw + (FC,))
+                    ops.correlation(c, feat_b, feat_b1, bev_hw + (FC,),
                                     CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD, scratch['corr_map'])
-                    ops.crop_and_resize(c, scratch['corr_map'], (self.bev_h, self.bev_w, CORR_CH),
+                    ops.crop_and_resize(c, scratch['corr_map'], bev_hw + (CORR_CH,),
                                         b['top_bev'], self.P, b['top_count'], (ROI, ROI),
                                         b['corr_rois'])
                     self._mark(c, st['step'], 'tail%d_corrmap' % f)
@@ -362,7 +417,8 @@ class FramePairPipeline(object):
                                                 b['orientations'])
             ops.pack_detections(
                 c, b['boxes_3d'], b['det_scores'], b['det_idx'], b['det_count'], MAX_DET,
-                float(f % 2), self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
+                float(f % self.fps),
+                self.d_records.offset(4 * MAX_DET * REC_COLS * f, (MAX_DET, REC_COLS)),
                 self.d_rec_counts.offset(4 * f, (1,), np.int32), d_corr_offsets=corr_offsets,
                 d_orientations=b['orientations'] if self.box_4ca else None)
             self._mark(c, st['step'], 'tail%d_end' % f)
@@ -383,7 +439,8 @@ class FramePairPipeline(object):
             return 0.0
         counts = anchor_counts or self.last_anchor_counts
         return (sum(self.rpn_head.flops(a) for a in counts)
-                + self.nf * self.avod_head.flops(self.P) + self.pairs * self.corr_head.flops(self.P))
+                + self.nf * self.avod_head.flops(self.P)
+                + (self.pairs * self.corr_head.flops(self.P) if self.corr_head else 0.0))
 
     def flops_per_pair(self):
         return self.flops_per_step() / self.pairs

@@ -3,18 +3,12 @@
 benchmarks and parity tests run on these."""
 import numpy as np
 
-# avod/tests/datasets/Kitti/tracking/training/calib/0000.txt (numbers only)
-P2 = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01],
-               [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01],
-               [0.0, 0.0, 1.0, 2.745884e-03]])
-R0_RECT = np.array([[9.999239e-01, 9.837760e-03, -7.445048e-03],
-                    [-9.869795e-03, 9.999421e-01, -4.278459e-03],
-                    [7.402527e-03, 4.351614e-03, 9.999631e-01]])
-TR_VELO_TO_CAM = np.array(
-    [[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
-     [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
-     [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01]])
-IMAGE_WH = (1242, 375)
+from dodt_amd import config as _config
+
+P2 = _config.KITTI_P2
+R0_RECT = _config.KITTI_R0_RECT
+TR_VELO_TO_CAM = _config.KITTI_TR_VELO_TO_CAM
+IMAGE_WH = _config.KITTI_IMAGE_WH
 
 PYRAMID_CHANNELS = {
     'conv1_1': (None, 32), 'conv1_2': (32, 32),
@@ -29,12 +23,15 @@ PYRAMID_LAYERS = list(PYRAMID_CHANNELS.keys())
 TRANSPOSED = ('upconv3', 'upconv2', 'upconv1')
 
 
-def velo_to_cam(r0_rect=R0_RECT, tr=TR_VELO_TO_CAM):
-    """(3,4) = (R0_rect padded . Tr_velo_to_cam padded)[0:3], float64
-    (wavedata/.../calib_utils.py:502-519)."""
-    r0 = np.zeros((4, 4)); r0[:3, :3] = r0_rect; r0[3, 3] = 1
-    t = np.zeros((4, 4)); t[:3, :4] = tr; t[3, 3] = 1
-    return np.dot(r0, t)[:3]
+velo_to_cam = _config.velo_to_cam
+
+
+def pipeline_weights(cfg):
+    """Random-init extractor weights of cfg's architecture for FramePipeline(bev_params=,
+    img_params=): seeds 42 (BEV) and 142 (image), the ones every parity test uses."""
+    plain = cfg['extractor'] == 'vgg'
+    return dict(bev_params=pyramid_params(cfg['bev_depth'], 42, plain=plain),
+                img_params=pyramid_params(cfg['img_depth'], 142, plain=plain))
 
 
 def frame_seed(seq, frame):

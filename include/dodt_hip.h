@@ -66,9 +66,16 @@ int dodt_free(dodt_ctx* ctx, void* d_ptr);
 int dodt_memcpy_h2d(dodt_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int dodt_memcpy_d2h(dodt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int dodt_memset(dodt_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* Page-locked host memory and copies from it that do not block the host: the way raw frames
+ * (velodyne .bin contents, camera images -- what KittiUtils hands to create_feed_dict,
+ * avod/core/models/dt_rpn_model.py:865-1042) reach the device under the previous step's
+ * kernels.  The source must stay untouched until the stream has passed the copy. */
+int dodt_pinned_alloc(dodt_ctx* ctx, size_t bytes, void** out);
+int dodt_pinned_free(dodt_ctx* ctx, void* ptr);
+int dodt_memcpy_h2d_async(dodt_ctx* ctx, void* d_dst, const void* pinned_src, size_t bytes);
 
 /* Small device->host reads that do not stall the stream: begin enqueues a copy of
- * n <= 16 int32 into pinned slot `slot` (0..7) and records an event; end waits for
+ * n <= 16 int32 into pinned slot `slot` (0..31) and records an event; end waits for
  * that event only (kernels enqueued after begin keep running) and returns the
  * values.  Used to learn the kept-anchor count while the conv stacks run. */
 int dodt_fetch_i32_begin(dodt_ctx* ctx, const int32_t* d_src, int n, int slot);

@@ -129,10 +129,16 @@ def pair_detections_computed(inps, feats, head_params, cfg, p2, image_wh, rpn_nm
     return outs
 
 
-def extract(bev, img_u8, bev_params, img_params, img_hw):
-    """Both extractors + bottlenecks for one frame."""
-    bev_feat = oext.vgg_pyramid(bev, bev_params, pad_top=4)
+def extract(bev, img_u8, bev_params, img_params, img_hw, extractor='vgg_pyr'):
+    """Both extractors + bottlenecks for one frame.  extractor 'vgg_pyr': the pyramid nets of
+    the DODT config; 'vgg': the plain VGG nets of avod_cars_example (bev_vgg.py / img_vgg.py:
+    4x-upsampled conv4_3, 256 channels, no top padding)."""
     pre = tfops.img_preprocess(img_u8, img_hw[0], img_hw[1])
-    img_feat = oext.vgg_pyramid(pre, img_params, pad_top=0)
+    if extractor == 'vgg':
+        bev_feat = oext.vgg_plain(bev, bev_params)
+        img_feat = oext.vgg_plain(pre, img_params)
+    else:
+        bev_feat = oext.vgg_pyramid(bev, bev_params, pad_top=4)
+        img_feat = oext.vgg_pyramid(pre, img_params, pad_top=0)
     return (bev_feat, img_feat, oext.bottleneck_1x1(bev_feat, bev_params['bottleneck']),
             oext.bottleneck_1x1(img_feat, img_params['bottleneck']))

@@ -136,7 +136,7 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
     # boundary may round the other way (1 ulp = 2^-8 of that element) and shift the next
     # layer's outputs; after four layers up to ~2e-3 of the output scale
     tol = 1e-4 if head_dtype == 'f32' else 5e-3
-    pipe = FramePairPipeline(ctx, C, rpn_nms_size=1024, head_params=hp, conv_dtype=conv_dtype,
+    pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=1024, head_params=hp, conv_dtype=conv_dtype,
                              head_dtype=head_dtype)
     frames = (0, 2)
     pts = [synth.lidar_frame(4, f) for f in frames]

@@ -14,7 +14,7 @@ C = config.PYRAMID_DODT
 @pytest.fixture(scope='module')
 def setup():
     ctx = device.default_context()
-    pipe = FramePairPipeline(ctx, C, rpn_nms_size=1024)
+    pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=1024)
     return ctx, pipe
 
 
@@ -36,7 +36,7 @@ def test_frame_pair_matches_oracle(setup, conv_dtype):
     """'f32s' (split mode on the bf16 MFMA) is held to the same bars as the fp32 MFMA path."""
     ctx, pipe = setup
     if conv_dtype != 'f32':
-        pipe = FramePairPipeline(ctx, C, rpn_nms_size=1024, conv_dtype=conv_dtype,
+        pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=1024, conv_dtype=conv_dtype,
                                  reuse_streams_of=pipe)
     pts, imgs, heads, counts = _run(ctx, pipe, seq=0, frames=(0, 2))    # tau = 2
     recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
@@ -85,7 +85,7 @@ def test_frame_pair_matches_oracle(setup, conv_dtype):
 def test_two_pairs_per_step_match_single_pair_steps(setup):
     """Batching pairs through the conv stacks and the side streams changes nothing."""
     ctx, pipe1 = setup
-    pipe2 = FramePairPipeline(ctx, C, rpn_nms_size=1024, pairs_per_step=2)
+    pipe2 = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=1024, pairs_per_step=2)
     frames = [(3, 0), (3, 2), (5, 1), (5, 3)]
     pts = [synth.lidar_frame(s, f) for s, f in frames]
     imgs = [synth.image_frame(s, f) for s, f in frames]
@@ -165,7 +165,7 @@ def test_dense_scene_300k_points_4096_proposals():
     """BASELINE.json configs[4]'s shape (300k points per frame, 4096 proposals): voxeliser,
     anchor filter, both NMS stages and the decoders against the oracle, indices exact."""
     ctx = device.default_context()
-    pipe = FramePairPipeline(ctx, C, n_points_max=300000, rpn_nms_size=4096)
+    pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), n_points_max=300000, rpn_nms_size=4096)
     pts, imgs, heads, counts = _run(ctx, pipe, seq=9, frames=(0, 3), n_points=300000)   # tau = 3
     recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
     for f in range(2):
@@ -185,3 +185,80 @@ def test_dense_scene_300k_points_4096_proposals():
         assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
         np.testing.assert_allclose(recs[f], want['records'], rtol=1e-5, atol=1e-4)
     pipe.close()
+
+
+def test_single_frame_cars_example_matches_oracle():
+    """BASELINE.json configs[0]: the AVOD cars_example configuration -- plain VGG extractors
+    (bev_vgg / img_vgg, 256-channel maps at half resolution), image resized to 480 x 1590,
+    256 -> 1 bottlenecks, single frames (rpn_model.py / avod_model.py: no pair, no correlation
+    branch), rpn_test_nms_size 300.  Same bars as the frame-pair test."""
+    cfg = config.CARS_EXAMPLE
+    ctx = device.default_context()
+    w = synth.pipeline_weights(cfg)
+    pipe = FramePairPipeline(ctx, cfg, rpn_nms_size=cfg['rpn_test_nms_size'], **w)
+    assert pipe.fps == 1 and pipe.nf == 1
+    assert (pipe.bev_fh, pipe.bev_fw, pipe.feat_c) == (350, 400, 256)
+    assert (pipe.img_fh, pipe.img_fw) == (240, 795)
+    assert abs(pipe.flops_per_step() - 185.85e9) < 0.1e9        # BASELINE.md section 3
+    pts, imgs, heads, counts = _run(ctx, pipe, seq=11, frames=(0,))
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    b = pipe.fr[0]
+    inp = opipe.frame_inputs(pts[0], cfg, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                             synth.IMAGE_WH)
+    A = len(inp['keep'])
+    assert counts[0] == A and A > 1000
+    assert np.array_equal(b['keep'].download()[:A], inp['keep'])
+    assert np.array_equal(b['img_norm'].download()[:A], inp['img_norm_tf'])
+    assert np.array_equal(pipe.d_bev_in[0].download(), inp['bev'])
+    feats = opipe.extract(inp['bev'], imgs[0], w['bev_params'], w['img_params'],
+                          cfg['img_dims'], extractor='vgg')
+    assert feats[0].shape == (350, 400, 256) and feats[1].shape == (240, 795, 256)
+    want = opipe.frame_detections(inp, heads[0], cfg, synth.P2, synth.IMAGE_WH, pipe.P, *feats,
+                                  frame_mark=0)
+    n_top = int(b['top_count'].download()[0])
+    assert n_top == len(want['top_idx']) <= 300
+    assert np.array_equal(b['top_idx'].download()[:n_top], want['top_idx'])
+    n_det = int(b['det_count'].download()[0])
+    assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
+    want_rec = want['records'].copy()
+    want_rec[:, 9:16] = 0        # single-frame AVOD has no correlation-shifted box
+    np.testing.assert_allclose(recs[0], want_rec, rtol=1e-5, atol=1e-4)
+    for name in ('rpn_bev_roi', 'rpn_img_roi', 'bev_rois', 'img_rois'):
+        got = b[name].download()[:len(want[name])]
+        scale = np.abs(want[name]).max() + 1e-12
+        assert np.abs(got - want[name]).max() <= 5e-4 * scale, name
+    pipe.close()
+
+
+def test_run_from_pinned_host_inputs_matches_resident_inputs(setup):
+    """run_from_host(): raw frames start in page-locked host memory and reach the device by
+    asynchronous copies on the prep streams; same detections as with resident inputs,
+    also when steps are pipelined and the pinned buffers alternate."""
+    ctx, pipe = setup
+    want = []
+    for seq in (12, 13):
+        _run(ctx, pipe, seq=seq, frames=(0, 2))
+        want.append(pipe.d_records.download().copy())
+    hosts = []
+    for seq in (12, 13):
+        pts = [synth.lidar_frame(seq, f) for f in (0, 2)]
+        imgs = [synth.image_frame(seq, f) for f in (0, 2)]
+        hp = [ctx.pinned((pipe.n_points_max, 4), np.float32) for _ in pts]
+        hi = [ctx.pinned(i.shape, np.uint8) for i in imgs]
+        for a, p in zip(hp, pts):
+            a.a[:len(p)] = p
+        for a, i in zip(hi, imgs):
+            a.a[...] = i
+        heads = [{k: ctx.array(v) for k, v in synth.head_outputs(seq, f, pipe.n_all, pipe.P).items()}
+                 for f in (0, 2)]
+        hosts.append((hp, [len(p) for p in pts], hi, heads))
+    pipe.run_from_host(*hosts[0])
+    pipe.run_from_host(*hosts[1])
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), want[0])
+    pipe.finish()
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), want[1])
+    for hp, _, hi, _ in hosts:
+        for a in hp + hi:
+            a.free()

@@ -5,7 +5,7 @@ from dodt_amd import config, device, synth, ops
 from dodt_amd.pipeline import FramePairPipeline
 import dodt_amd.pipeline as P
 ctx = device.default_context()
-pipe = FramePairPipeline(ctx, config.PYRAMID_DODT, head_params=synth.head_params())
+pipe = FramePairPipeline(ctx, config.PYRAMID_DODT, **synth.pipeline_weights(config.PYRAMID_DODT), head_params=synth.head_params())
 pts = [ctx.array(synth.lidar_frame(0, f)) for f in (0, 2)]
 imgs = [ctx.array(synth.image_frame(0, f)) for f in (0, 2)]
 n = [120000, 120000]

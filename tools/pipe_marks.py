@@ -12,7 +12,7 @@ from dodt_amd.pipeline import FramePairPipeline  # noqa: E402
 computed = '--injected' not in sys.argv
 conv_dtype = 'bf16' if '--bf16' in sys.argv else 'f32'
 ctx = device.default_context()
-pipe = FramePairPipeline(ctx, config.PYRAMID_DODT,
+pipe = FramePairPipeline(ctx, config.PYRAMID_DODT, **synth.pipeline_weights(config.PYRAMID_DODT),
                          head_params=synth.head_params() if computed else None,
                          conv_dtype=conv_dtype)
 frames = (0, 2)
