@@ -41,6 +41,10 @@ class BevParams(C.Structure):
         ('height_hi', C.c_double),
         ('occ_lo', C.c_double),
         ('occ_hi', C.c_double),
+        ('has_pre_transform', C.c_int32),
+        ('reserved_', C.c_int32),
+        ('pre_translate', C.c_double * 3),
+        ('pre_rotate', C.c_double * 9),
     ]
 
 

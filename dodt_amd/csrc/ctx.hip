@@ -37,7 +37,7 @@ void Scratch::release() {
 
 extern "C" {
 
-int dodt_version(void) { return 2; }
+int dodt_version(void) { return 3; }
 
 const char* dodt_last_error(void) { return dodt::g_last_error.c_str(); }
 

@@ -33,6 +33,8 @@ struct VoxParams {
     int cx_min, cy_min, cz_min;
     int occ_words_per_row;
     int origin_off;  // word offset of cell (x=0, z=0), channel 0; -1 if outside
+    int has_pre;     // ego-motion warp in the velodyne frame in front of everything else
+    double pre_t[3], pre_r[9];
     double m[12];
     double p2[12];
     double im_w, im_h;
@@ -52,11 +54,21 @@ constexpr int kCntList = 0, kCntErr = 1, kCntSlice = 2;
 
 // Point i in the rectified camera frame.  Sum order = k ascending fma chain,
 // which is what a BLAS dgemm micro-kernel does for the reference's np.dot.
+// warp (velodyne input only): the ego-motion registration of a pair's second frame,
+// point_cloud_transform (avod/datasets/kitti/kitti_tracking_dataset.py:324-335): the float32
+// xyz become float64, (p + trans) @ matrix, and are stored back into the float32 array the
+// points came from -- one rounding to float32 -- before lidar_to_cam_frame reads them.
 __device__ __forceinline__ bool load_point(const void* pts, const VoxParams& P, int i,
-                                           double& x, double& y, double& z) {
+                                           double& x, double& y, double& z, bool warp = true) {
     if (P.format == DODT_PTS_VELO_XYZI) {
         const float4 v = reinterpret_cast<const float4*>(pts)[i];
-        const double vx = v.x, vy = v.y, vz = v.z;
+        double vx = v.x, vy = v.y, vz = v.z;
+        if (warp && P.has_pre) {
+            const double ax = vx + P.pre_t[0], ay = vy + P.pre_t[1], az = vz + P.pre_t[2];
+            vx = (double)(float)fma(az, P.pre_r[6], fma(ay, P.pre_r[3], ax * P.pre_r[0]));
+            vy = (double)(float)fma(az, P.pre_r[7], fma(ay, P.pre_r[4], ax * P.pre_r[1]));
+            vz = (double)(float)fma(az, P.pre_r[8], fma(ay, P.pre_r[5], ax * P.pre_r[2]));
+        }
         x = fma(P.m[2], vz, fma(P.m[1], vy, P.m[0] * vx)) + P.m[3];
         y = fma(P.m[6], vz, fma(P.m[5], vy, P.m[4] * vx)) + P.m[7];
         z = fma(P.m[10], vz, fma(P.m[9], vy, P.m[8] * vx)) + P.m[11];
@@ -73,6 +85,11 @@ __device__ __forceinline__ bool load_point(const void* pts, const VoxParams& P, 
         z = p[2 * (size_t)P.n + i];
         return true;
     }
+}
+
+__device__ __forceinline__ bool in_extents(const VoxParams& P, double x, double y, double z) {
+    return x > P.ext[0] && x < P.ext[1] && y > P.ext[2] && y < P.ext[3] && z > P.ext[4] &&
+           z < P.ext[5];
 }
 
 __global__ void __launch_bounds__(256)
@@ -94,8 +111,10 @@ vox_scatter(const void* __restrict__ pts, const VoxParams P, uint32_t* __restric
     const int i = blockIdx.x * blockDim.x + tid;
     double x, y, z;
     bool ok = i < P.n && load_point(pts, P, i, x, y, z);
-    ok = ok && (x > P.ext[0] && x < P.ext[1] && y > P.ext[2] && y < P.ext[3] && z > P.ext[4] &&
-                z < P.ext[5]);
+    ok = ok && in_extents(P, x, y, z);
+    bool occ_ok = ok;
+    double occ_dotp = 0.0;
+    int occ_xi = 0, occ_zi = 0;
     if (ok) {
         // (plane + [0,0,0,-off]) . [x,y,z,1] < 0 ; d - off is folded on the host
         const double dotp = fma(P.c, z, fma(P.b, y, P.a * x));
@@ -104,6 +123,7 @@ vox_scatter(const void* __restrict__ pts, const VoxParams P, uint32_t* __restric
         const int zi = (int)floor(z / P.vs) - P.cz_min;
         if (xi < 0 || xi >= P.X || zi < 0 || zi >= P.Z || yb < 0 || yb > 126) {
             atomicOr(&counters[kCntErr], 1u);  // reference: ValueError("Extents are smaller ...")
+            occ_ok = false;
         } else {
             const int C = P.S + 1;
             const uint32_t base = (uint32_t)(((P.Z - 1 - zi) * P.X + xi) * C);
@@ -120,19 +140,41 @@ vox_scatter(const void* __restrict__ pts, const VoxParams P, uint32_t* __restric
                 const uint32_t old = atomicAdd(&out[base + P.S], 1u);
                 if (old == 0u) s_items[atomicAdd(&s_n, 1u)] = base + P.S;
             }
-            if (occ != nullptr &&
-                (((dotp + P.occ_d_hi) < 0.0) != ((dotp + P.occ_d_lo) < 0.0))) {
-                atomicOr(&occ[zi * P.occ_words_per_row + (xi >> 5)], 1u << (xi & 31));
+            occ_dotp = dotp;
+            occ_xi = xi;
+            occ_zi = zi;
+        }
+    }
+    if (occ != nullptr) {
+        // The anchor filter's grid comes from the cloud as read from the file: the reference
+        // re-reads it without the ego-motion warp (kitti_tracking_utils.py:98-126 ->
+        // tracking_utils.get_lidar_point_cloud) -- reproduced, not fixed
+        if (P.has_pre && P.format == DODT_PTS_VELO_XYZI) {
+            double ux, uy, uz;
+            occ_ok = i < P.n && load_point(pts, P, i, ux, uy, uz, false) && in_extents(P, ux, uy, uz);
+            if (occ_ok) {
+                occ_dotp = fma(P.c, uz, fma(P.b, uy, P.a * ux));
+                occ_xi = (int)floor(ux / P.vs) - P.cx_min;
+                occ_zi = (int)floor(uz / P.vs) - P.cz_min;
+                const int yb = (int)floor(uy / P.vs) - P.cy_min;
+                if (occ_xi < 0 || occ_xi >= P.X || occ_zi < 0 || occ_zi >= P.Z || yb < 0 || yb > 126) {
+                    atomicOr(&counters[kCntErr], 1u);
+                    occ_ok = false;
+                }
             }
         }
+        if (occ_ok && (((occ_dotp + P.occ_d_hi) < 0.0) != ((occ_dotp + P.occ_d_lo) < 0.0)))
+            atomicOr(&occ[occ_zi * P.occ_words_per_row + (occ_xi >> 5)], 1u << (occ_xi & 31));
     }
     __syncthreads();
     if (tid < P.S && s_cnt[tid]) atomicAdd(&counters[kCntSlice + tid], s_cnt[tid]);
     if (tid == 0) s_base = s_n ? atomicAdd(&counters[kCntList], s_n) : 0u;
     __syncthreads();
     const uint32_t n = s_n, gbase = s_base;
-    for (uint32_t k = tid; k < n; k += 256)
+    for (uint32_t k = tid; k < n; k += 256) {
         if (gbase + k < list_cap) list[gbase + k] = s_items[k];
+        else atomicOr(&counters[kCntErr], 2u);     // cannot happen with cap = 3 n; reported
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -208,6 +250,11 @@ extern "C" int dodt_bev_slices(dodt_ctx* ctx, const void* d_points, int n_points
     P.cz_min = (int)minz;
     P.occ_words_per_row = dodt::ceil_div(P.X, 32);
     for (int k = 0; k < 12; ++k) { P.m[k] = bp->velo_to_cam[k]; P.p2[k] = bp->p2[k]; }
+    P.has_pre = bp->has_pre_transform != 0;
+    DODT_REQUIRE(!P.has_pre || bp->point_format == DODT_PTS_VELO_XYZI,
+                 "dodt_bev_slices: the ego-motion pre-transform applies to velodyne points");
+    for (int k = 0; k < 3; ++k) P.pre_t[k] = bp->pre_translate[k];
+    for (int k = 0; k < 9; ++k) P.pre_r[k] = bp->pre_rotate[k];
     P.im_w = bp->im_w;
     P.im_h = bp->im_h;
     P.a = bp->plane[0]; P.b = bp->plane[1]; P.c = bp->plane[2]; P.d = bp->plane[3];
@@ -277,6 +324,6 @@ extern "C" int dodt_bev_status(dodt_ctx* ctx, int* flags) {
     DODT_HIP_CHECK(hipMemcpyAsync(host, ctx->vox_ws.ptr, sizeof(host), hipMemcpyDeviceToHost,
                                   ctx->stream));
     DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    *flags = (int)(host[kCntErr] & 1u);
+    *flags = (int)(host[kCntErr] & 3u);
     return DODT_OK;
 }

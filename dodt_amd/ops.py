@@ -41,6 +41,21 @@ def make_bev_params(cfg, velo_to_cam=None, p2=None, im_wh=None,
     bp.height_hi = float(cfg['height_hi'])
     bp.occ_lo = float(cfg['anchor_filter_lo'])
     bp.occ_hi = float(cfg['anchor_filter_hi'])
+    bp.has_pre_transform = 0
+    return bp
+
+
+def with_ego_motion(bev_params, trans, matrix):
+    """Copy of bev_params that registers a pair's second frame into the first frame's
+    coordinates first: p' = (p + trans) @ matrix in the velodyne frame
+    (kitti_tracking_dataset.py:303-335; trans, matrix from
+    dodt_amd.datasets.kitti.kitti_tracking_utils.coordinate_transform)."""
+    bp = _lib.BevParams.from_buffer_copy(bev_params)
+    t = np.asarray(trans, np.float64).reshape(3)
+    m = np.asarray(matrix, np.float64).reshape(9)
+    bp.has_pre_transform = 1
+    bp.pre_translate = (C.c_double * 3)(*t)
+    bp.pre_rotate = (C.c_double * 9)(*m)
     return bp
 
 

@@ -224,7 +224,7 @@ class FramePairPipeline(object):
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]
 
     # ------------------------------------------------------------------------------------
-    def run_from_host(self, h_points, n_points, h_images, heads=None):
+    def run_from_host(self, h_points, n_points, h_images, heads=None, ego_motion=None):
         """run() for raw frames still in (page-locked) host memory: lists of PinnedArray --
         points (n_max,4) float32 of which n_points[f] rows are valid, images (H,W,3) uint8.
         The copies are enqueued on each frame's prep stream in front of its prep kernels, so
@@ -248,15 +248,19 @@ class FramePairPipeline(object):
             di.upload_async(h_images[f], ctx=c)
             d_pts.append(dp)
             d_imgs.append(di)
-        return self.run(d_pts, n_points, d_imgs, heads)
+        return self.run(d_pts, n_points, d_imgs, heads, ego_motion)
 
-    def run(self, d_points, n_points, d_images, heads=None):
+    def run(self, d_points, n_points, d_images, heads=None, ego_motion=None):
         """Enqueue one step.  Lists of length 2 * pairs_per_step, frame order
         [pair0 f0, pair0 f1, pair1 f0, ...]: d_points[f] (n,4) float32 velodyne xyzi;
         d_images[f] (H,W,3) uint8; heads[f] dict of device arrays rpn_logits (N,2),
         rpn_offsets (N,6), cls_logits (P,2), offsets_4c (P,10), angle_vectors (P,2) (box_4ca)
         [, corr_offsets (P,3) on frame 0 of a pair]; None when the pipeline computes the heads
         itself (head_params).
+        ego_motion: None, or one (trans (3,), matrix (3,3)) per pair of the step -- the
+        registration of the pair's second frame into the first frame's coordinates
+        (datasets.kitti.kitti_tracking_utils.coordinate_transform; applied to the second
+        frame's BEV maps, not to its anchor-filter grid, like the reference).
         Returns the parity (0/1) of the record buffers this step will fill.  The
         detections of the PREVIOUS step are complete on the main stream when this returns
         (self.d_records / self.fr / self.last_anchor_counts then describe that step);
@@ -277,7 +281,11 @@ class FramePairPipeline(object):
         for f in range(nf):
             c, b = self.preps[f % ns], fr[f]
             self._mark(c, k, 'prep%d_start' % f)
-            ops.bev_slices(c, d_points[f], n_points[f], self.bp, bev_in[f], b['occ'])
+            bp = self.bp
+            if ego_motion is not None and self.fps == 2 and f % 2 == 1 \
+                    and ego_motion[f // 2] is not None:
+                bp = ops.with_ego_motion(self.bp, *ego_motion[f // 2])
+            ops.bev_slices(c, d_points[f], n_points[f], bp, bev_in[f], b['occ'])
             ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
                               b['keep'], b['count'])
             ops.fetch_i32_begin(c, b['count'], 1, 2 * f + cur)

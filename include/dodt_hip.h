@@ -106,6 +106,20 @@ typedef struct dodt_bev_params {
     double voxel_size;        /* float32-rounded 0.1 as python sees it (F7)         */
     double height_lo, height_hi;
     double occ_lo, occ_hi;    /* slice of the anchor-filter occupancy grid (0.2,2.0) */
+    /* Ego-motion registration of the second frame of a pair into the first frame's
+     * coordinates, KittiTrackingDataset.point_cloud_transform
+     * (avod/datasets/kitti/kitti_tracking_dataset.py:303-335, call site :489):
+     * p' = float32((p + pre_translate) @ pre_rotate) in the VELODYNE frame (float64 arithmetic,
+     * one rounding into the float32 cloud, as the reference stores it), applied in front of
+     * velo_to_cam when has_pre_transform != 0 (DODT_PTS_VELO_XYZI only).  pre_rotate is (3,3)
+     * row major = Rz . Rx . Ry of Oxts.get_rotate_matrix (kitti_tracking_utils.py:147-215).
+     * The BEV maps come from the warped cloud; the occupancy bits for the anchor filter from
+     * the UN-warped one, because the reference re-reads the raw file for that grid
+     * (kitti_tracking_utils.py:98-126) -- reproduced, not fixed. */
+    int32_t has_pre_transform;
+    int32_t reserved_;
+    double pre_translate[3];
+    double pre_rotate[9];
 } dodt_bev_params;
 
 /* d_bev_out: (Z, X, num_slices+1) float32, Z = 700 rows, X = 800 cols for the

@@ -11,10 +11,18 @@ from oracle import points as opoints
 from oracle import tfops
 
 
-def frame_inputs(xyzi, cfg, r0, tr, p2, image_wh):
-    """The data half: BEV input, kept anchors and their projections."""
+def frame_inputs(xyzi, cfg, r0, tr, p2, image_wh, ego_motion=None):
+    """The data half: BEV input, kept anchors and their projections.  ego_motion = (trans,
+    matrix): the frame is the second one of a pair and is registered into the first frame's
+    coordinates first (kitti_tracking_dataset.py:303-335) -- for the BEV maps only: the
+    anchor filter's grid is built from the cloud as read from the file
+    (kitti_tracking_utils.py:98-126)."""
     cloud = opoints.lidar_in_camera_view(xyzi, r0, tr, p2, image_wh)
-    bev = opoints.bev_input(cloud, cfg['ground_plane'], cfg['area_extents'],
+    bev_cloud = cloud
+    if ego_motion is not None:
+        bev_cloud = opoints.lidar_in_camera_view(
+            opoints.point_cloud_transform(xyzi, *ego_motion), r0, tr, p2, image_wh)
+    bev = opoints.bev_input(bev_cloud, cfg['ground_plane'], cfg['area_extents'],
                             cfg['voxel_size'], cfg['height_lo'], cfg['height_hi'],
                             cfg['num_slices']).astype(np.float32)
     boxes = oanchors.tile_anchors_3d(cfg['area_extents'], cfg['anchor_sizes'],

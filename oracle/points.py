@@ -254,3 +254,13 @@ def bev_input(point_cloud_3xn, ground_plane, area_extents, voxel_size,
     b = generate_bev(point_cloud_3xn, ground_plane, area_extents, voxel_size,
                      height_lo, height_hi, num_slices)
     return np.dstack(b['height_maps'] + [b['density_map']])
+
+
+def point_cloud_transform(xyzi_velo, trans, matrix):
+    """KittiTrackingDataset.point_cloud_transform (avod/datasets/kitti/
+    kitti_tracking_dataset.py:324-335): the pair's second frame registered into the first
+    frame's velodyne coordinates, (p + trans) @ matrix in float64, stored back into the float32
+    cloud (one rounding) -- pinned by tests/golden/egomotion.npz."""
+    out = np.array(xyzi_velo, dtype=np.float32, copy=True)
+    out[:, :3] = (out[:, :3] + np.asarray(trans, np.float64)) @ np.asarray(matrix, np.float64)
+    return out

@@ -262,3 +262,40 @@ def test_run_from_pinned_host_inputs_matches_resident_inputs(setup):
     for hp, _, hi, _ in hosts:
         for a in hp + hi:
             a.free()
+
+
+def test_pair_with_ego_motion_matches_oracle(setup):
+    """A pair whose second frame is registered by an OXTS-derived ego-motion: frame 1's BEV
+    input comes from the warped cloud, its kept anchors from the raw one; frame 0 unchanged."""
+    from dodt_amd.datasets.kitti import kitti_tracking_utils as ktu
+    ctx, pipe = setup
+    cur = ktu.Oxts('49.011 8.4228 112.8 0.0224 0.0010 -1.2219')
+    nxt = ktu.Oxts('49.011004 8.422806 112.8 0.0201 0.0031 -1.2419')
+    trans, matrix, _ = ktu.coordinate_transform(cur, nxt)
+    assert 0.3 < np.linalg.norm(trans) < 2.0
+    pts = [synth.lidar_frame(14, f) for f in (0, 2)]
+    imgs = [synth.image_frame(14, f) for f in (0, 2)]
+    heads = [synth.head_outputs(14, f, pipe.n_all, pipe.P) for f in (0, 2)]
+    pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts], [ctx.array(i) for i in imgs],
+             [{k: ctx.array(v) for k, v in h.items()} for h in heads],
+             ego_motion=[(trans, matrix)])
+    pipe.finish()
+    ctx.sync()
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    for f in range(2):
+        b = pipe.fr[f]
+        inp = opipe.frame_inputs(pts[f], C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                 synth.IMAGE_WH, ego_motion=(trans, matrix) if f == 1 else None)
+        A = len(inp['keep'])
+        assert pipe.last_anchor_counts[f] == A
+        assert np.array_equal(b['keep'].download()[:A], inp['keep'])
+        assert np.array_equal(pipe.d_bev_in[f].download(), inp['bev'])
+        want = opipe.frame_detections(inp, heads[f], C, synth.P2, synth.IMAGE_WH, pipe.P,
+                                      frame_mark=f)
+        n_det = int(b['det_count'].download()[0])
+        assert np.array_equal(b['det_idx'].download()[:n_det], want['det_idx'])
+        np.testing.assert_allclose(recs[f], want['records'], rtol=1e-5, atol=1e-4)
+    plain = opipe.frame_inputs(pts[1], C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                               synth.IMAGE_WH)
+    assert not np.array_equal(pipe.d_bev_in[1].download(), plain['bev'])
+    assert np.array_equal(pipe.fr[1]['keep'].download()[:len(plain['keep'])], plain['keep'])

@@ -215,3 +215,34 @@ def test_projector_dropins(frames, tag):
     with pytest.raises(ValueError):
         gpu_projector.project_to_image_space(np.zeros((3, 5)), frames[tag + '_p2'],
                                              [375, 1242])
+
+
+def test_bev_of_ego_motion_registered_frame_matches_reference(ctx, golden_dir):
+    """The second frame of a tracking pair (video 0000, frames 3 -> 5): dodt_bev_slices with
+    the ego-motion pre-transform against what the reference's point_cloud_transform ->
+    get_lidar_in_camera_view -> generate_bev produced (tests/golden/make_goldens_egomotion.py):
+    BEV maps of the registered cloud exact, occupancy bits of the UN-registered cloud exact
+    (kitti_tracking_utils.py:98-126: the reference re-reads the raw file for the filter)."""
+    g = np.load(os.path.join(golden_dir, 'egomotion.npz'))
+    bp = ops.with_ego_motion(
+        ops.make_bev_params(C, synth.velo_to_cam(g['r0'], g['tr']), g['p2'], g['imwh']),
+        g['trans'], g['matrix'])
+    d_out = ctx.empty((700, 800, 6), np.float32)
+    d_occ = ctx.empty((700, 25), np.uint32)
+    ops.bev_slices(ctx, ctx.array(g['xyzi']), len(g['xyzi']), bp, d_out, d_occ)
+    assert ops.bev_status(ctx) == 0
+    want = np.zeros((700, 800, 6))
+    want[g['bev_r'], g['bev_c'], g['bev_ch']] = g['bev_val']
+    _compare_bev(d_out.download(), want)
+    occ = np.unpackbits(g['occ_bits'])[:800 * 700].reshape(800, 700)
+    assert np.array_equal(d_occ.download(), gpu_anchor_filter.pack_occupancy(occ.astype(bool)))
+    # without the pre-transform the maps differ (the registration moves ~0.64 m)
+    ops.bev_slices(ctx, ctx.array(g['xyzi']), len(g['xyzi']),
+                   ops.make_bev_params(C, synth.velo_to_cam(g['r0'], g['tr']), g['p2'], g['imwh']),
+                   d_out, d_occ)
+    assert np.count_nonzero(d_out.download() != want.astype(np.float32)) > 1000
+    assert np.array_equal(d_occ.download(), gpu_anchor_filter.pack_occupancy(occ.astype(bool)))
+    # camera-frame input cannot be registered in the velodyne frame
+    bad = ops.with_ego_motion(ops.make_bev_params(C, point_format=1), g['trans'], g['matrix'])
+    with pytest.raises(ValueError):
+        ops.bev_slices(ctx, ctx.array(np.zeros((3, 8))), 8, bad, d_out)
