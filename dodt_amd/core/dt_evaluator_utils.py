@@ -9,9 +9,15 @@ scores candidate matches with a 3-D IoU whose base overlap is rasterised at 1 cm
 computed exactly by polygon clipping ("an exact polygon 3-D IoU") -- the
 association only uses argmax and `> 0`, and reproduces the reference's outputs on the golden
 cases (tests/test_temporal.py).  `recover(frame_index, rows)` stands for the reference's
-recovery_coordinate (OXTS ego-motion, dataset layer, out of scope); None keeps keyframe-0
-coordinates.
+recovery_coordinate (dodt_amd.datasets.kitti.kitti_tracking_utils.recovery_coordinate with the
+pair's OXTS-derived ego-motion); None keeps keyframe-0 coordinates.
+
+track_through_ious (avod/core/dt_evaluator_utils.py:436-511) is the tracker over a sequence
+of keyframe pairs: greedy IoU association of each track's last box, shifted by its
+correlation offsets, with the next pair's detections.
 """
+import copy
+
 import numpy as np
 
 
@@ -157,3 +163,63 @@ def interpolate_non_keyframe_predictions(predictions, n_frames, threshold, recov
                 out[i].append(o)
     out = [np.asarray(o, dtype=np.float64).reshape(-1, 13) for o in out]
     return [out[0]] + [rec(i, out[i]) for i in range(1, n_frames)]
+
+
+def _iou_3d_kitti(box3d_1, box3d_2):
+    """iou_3d of track_through_ious (dt_evaluator_utils.py:439-447) on KITTI-ordered boxes
+    [h, w, l, x, y, z, ry].  The reference builds its [ry, l, h, w, tx, ty, tz] rows with the
+    index list [-2, 0, 2, 1, 3, 4, 5]: the angle slot receives z, the l slot h and the h slot
+    l -- reproduced as written."""
+    def conv(b):
+        b = np.asarray(b, dtype=np.float64)
+        # reference slots: ry = b[-2], l = b[0], h = b[2], w = b[1], t = b[3:6]
+        return np.array([b[3], b[4], b[5], b[0], b[1], b[2], b[-2]])
+    return float(three_d_iou(conv(box3d_1), conv(box3d_2)[None])[0])
+
+
+def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_threshold, t_min):
+    """dt_evaluator_utils.py:436-511.  dets_for_track[k]: detections of pair k's first frame
+    (dicts with 'boxes3d' (7,) [h,w,l,x,y,z,ry], 'offsets' = the box shifted into the pair's
+    second frame, 'scores', ...); dets_for_ious[k]: detections the previous pair reported for
+    that same frame ([{}] for k = 0, dt_evaluator_utils.py:398).  Returns the finished tracks:
+    dicts 'trajectory' (list of detections), 'max_score', 'start_frame'.  The inputs are not
+    modified (the reference appends merged detections to them)."""
+    dets_for_track = copy.deepcopy(dets_for_track)
+    dets_for_ious = copy.deepcopy(dets_for_ious)
+
+    def merge_dets(dets, dets_iou):
+        merged = dets
+        for item1 in dets_iou:
+            if not any(_iou_3d_kitti(item1['boxes3d'], item2['boxes3d']) > 0 for item2 in dets):
+                item1['offsets'] = item1['boxes3d']
+                merged.append(item1)
+        return merged
+
+    tracks_active, tracks_finished = [], []
+    for frame_num, dets in enumerate(dets_for_track):
+        update_tracks = []
+        dets_iou = dets_for_ious[frame_num]
+        for track in tracks_active:
+            if len(dets) > 0:
+                if len(dets_iou) != len(dets):
+                    merged = merge_dets(dets, dets_iou)
+                    dets = copy.deepcopy(merged)
+                    dets_iou = copy.deepcopy(merged)
+                ious = [_iou_3d_kitti(track['trajectory'][-1]['offsets'], x['boxes3d'])
+                        for x in dets_iou]
+                best = int(np.argmax(ious))
+                if ious[best] > iou_threshold:
+                    track['trajectory'].append(dets[best])
+                    track['max_score'] = max(track['max_score'], dets[best]['scores'])
+                    update_tracks.append(track)
+                    del dets[best]
+                    del dets_iou[best]
+            if len(update_tracks) == 0 or track is not update_tracks[-1]:
+                if track['max_score'] >= high_threshold and len(track['trajectory']) >= t_min:
+                    tracks_finished.append(track)
+        new_tracks = [{'trajectory': [det], 'max_score': det['scores'], 'start_frame': frame_num}
+                      for det in dets]
+        tracks_active = update_tracks + new_tracks
+    tracks_finished += [t for t in tracks_active
+                        if t['max_score'] >= high_threshold and len(t['trajectory']) >= t_min]
+    return tracks_finished
