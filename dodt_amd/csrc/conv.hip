@@ -28,6 +28,7 @@ using dodt::ConvArgs;
 using dodt::KernelVariant;
 using dodt::Inst;
 using dodt::InstSmall;
+using dodt::InstWino;
 using dodt::tail_only;
 using dodt::f32x4;
 
@@ -58,6 +59,10 @@ const std::vector<KernelVariant>& variants() {
         Inst<16, 4, 4, 1, 64, true>::variant(),
         Inst<8, 4, 4, 1, 64, true>::variant(),
         Inst<4, 4, 4, 1, 64, true>::variant(),
+        // fp32 Winograd F(2x2,3x3): 16 x 16 px x 64 ch, 32 x 16 px x 32 ch
+        InstWino<1, 4>::variant(),
+        InstWino<2, 2>::variant(),
+        InstWino<1, 2>::variant(),    // 16 x 16 px x 32 ch, 128 accumulators: two workgroups per CU
     };
     static const std::vector<KernelVariant> all = [] {
         std::vector<KernelVariant> a = v;
@@ -75,8 +80,22 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     const bool small = Cin < dodt::kCK;
     int best = -1;
     double best_cost = 1e300;
+    // fp32 3x3 stride-1 convs with >= 4 chunks of input channels run as Winograd F(2x2,3x3)
+    // (2.25x fewer fp32 MFMA cycles); DODT_CONV_WINO=0 keeps the direct kernels
+    static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 0;
+    // 1: the 256-accumulator variants (one workgroup per CU), 2: the 128-accumulator variant
+    // (two workgroups per CU)
+    if (wino_mode > 0 && !deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
+        for (size_t i = 0; i < vs.size(); ++i) {
+            if (!vs[i].wino || Cout % vs[i].BN != 0) continue;
+            if ((wino_mode == 2) != (vs[i].blocks_per_cu == 2)) continue;
+            if (best < 0 || vs[i].BN > vs[best].BN) best = (int)i;
+        }
+        if (best >= 0) return best;
+    }
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
+        if (v.wino) continue;
         if (v.deconv != deconv || v.small_cin != small || v.tail_only || v.bf16 != bf16 ||
             v.parts != parts || Cout % v.BN != 0)
             continue;
@@ -274,6 +293,7 @@ struct dodt_extractor {
     std::vector<Layer> layers;
     float* d_bneck_w = nullptr;
     int* d_counters = nullptr;  // two work-item counters per layer, zeroed every forward
+    float* d_zeros = nullptr;   // a zero page (Winograd kernel: out-of-image pixels)
     float bneck_scale = 1.0f, bneck_shift = 0.0f;
     bool bneck_loaded = false;
     double flops = 0.0;
@@ -318,6 +338,9 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     {
         static const int dbg = getenv("DODT_CONV_DEBUG") ? atoi(getenv("DODT_CONV_DEBUG")) : 0;
         a.debug = dbg;
+        // DODT_CONV_STAMP_LAYER=<name>: in-kernel step stamps of that layer's launch (diagnostic)
+        static const char* stamp_layer = getenv("DODT_CONV_STAMP_LAYER");
+        if (stamp_layer && l.name == stamp_layer) a.debug |= 32;
     }
     a.counter = ex->d_counters + 2 * (&l - ex->layers.data()) + which;
     a.counter_base = ex->d_counters + 64;
@@ -333,6 +356,7 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.bneck_scale = ex->bneck_scale;
     a.bneck_shift = ex->bneck_shift;
     a.bneck_frame_stride = (long long)out_h * dst.W;
+    a.zeros = ex->d_zeros;
     // persistent workgroups: as many as stay resident, each walks items with that stride
     int grid_x = a.n_items;
     if (!v.small_cin) {
@@ -344,6 +368,17 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     dim3 grid(grid_x, 1);
     v.launch(a, grid, ex->ctx->stream);
     DODT_LAUNCH_CHECK();
+    if (a.debug & 32) {
+        int h[72];
+        (void)hipStreamSynchronize(ex->ctx->stream);
+        (void)hipMemcpy(h, ex->d_counters + 64 + 32, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[dodt] %s step stamps (cycles): issue | compute | wait copies | barrier | total\n",
+                l.name.c_str());
+        for (int k = 0; k < 12; ++k)
+            fprintf(stderr, "[dodt]   step %2d: %6d %6d %6d %6d   next-top %6d\n", k, h[k * 6 + 1] - h[k * 6],
+                    h[k * 6 + 2] - h[k * 6 + 1], h[k * 6 + 3] - h[k * 6 + 2], h[k * 6 + 4] - h[k * 6 + 3],
+                    k < 11 ? h[(k + 1) * 6] - h[k * 6] : 0);
+    }
     if (a.debug & 8) {   // diagnostic: print the in-kernel clock of this launch
         unsigned long long h[2] = {0, 0};
         (void)hipStreamSynchronize(ex->ctx->stream);
@@ -357,6 +392,7 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
 
 // a variant's waves hold both rows of every 2x2 pooling window (conv_kernels.h kCanPool)
 bool variant_can_pool(const KernelVariant& v) {
+    if (v.wino) return true;   // a lane's 2x2 outputs are one pooling window
     const int rows_per_mt = 32 / v.TW, mt = v.MTB / v.WM;
     return !v.deconv && !v.small_cin && (rows_per_mt >= 2 || mt % 2 == 0) && v.TH % 2 == 0;
 }
@@ -393,7 +429,7 @@ void plan_layer(Layer& l, int batch, int num_cus, bool allow_tail, std::vector<i
                 for (int x = 0; x < tx; ++x) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
     l.main.variant = l.variant;
     l.tail.variant = -1;
-    if (v.small_cin) return;
+    if (v.small_cin || v.wino) return;
     static const bool no_tail = getenv("DODT_CONV_NO_TAIL") != nullptr;
     const int n = (int)main_items.size();
     const int G = num_cus * v.blocks_per_cu;
@@ -520,7 +556,10 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
             return DODT_ERR_HIP;
         }
     }
-    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 128 * sizeof(int)));
+    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 512 * sizeof(int)));
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 512 * sizeof(int), ctx->stream));
+    DODT_HIP_CHECK(hipMalloc(&ex->d_zeros, 256));
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_zeros, 0, 256, ctx->stream));
     // the pad rows of X0 stay zero for the life of the extractor
     DODT_HIP_CHECK(hipMemsetAsync(ex->buf[X0].ptr, 0,
                                   ex->buf[X0].frame_floats() * batch * sizeof(float), ctx->stream));
@@ -605,6 +644,7 @@ int dodt_extractor_destroy(dodt_extractor* ex) {
     }
     if (ex->d_bneck_w) (void)hipFree(ex->d_bneck_w);
     if (ex->d_counters) (void)hipFree(ex->d_counters);
+    if (ex->d_zeros) (void)hipFree(ex->d_zeros);
     delete ex;
     return DODT_OK;
 }
@@ -643,6 +683,38 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     }
     const KernelVariant& v = variants()[ln->variant];
     const int nchunks = l.Cin / v.CK;
+    if (v.wino) {
+        // Winograd filter transform U = G g G^T (float64 on the host, rounded once to fp32),
+        // G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]; blocked like the direct kernel's
+        // weights with the 16 points in place of the 9 taps: [n-tile][chunk][xi][h][n][4]
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        std::vector<float> u((size_t)16 * l.Cin * l.Cout, 0.0f);
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) {
+                double gk[3][3], tmp[4][3];
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        gk[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
+                for (int i = 0; i < 4; ++i)
+                    for (int kx = 0; kx < 3; ++kx)
+                        tmp[i][kx] = G[i][0] * gk[0][kx] + G[i][1] * gk[1][kx] + G[i][2] * gk[2][kx];
+                // [n-tile][chunk][xi][g = c/2][cb pair][t][cb & 1][k = c%2]: a lane (t, g) of the
+                // kernel reads 16 bytes = its (2g, 2g+1) channel pair for two 16-channel blocks
+                const int nt = co / v.BN, n = co % v.BN, ch = ci / 8, c = ci % 8;
+                const int cb = n / 16, t = n % 16, cbp = v.BN / 32;
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        const double val = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                        u[((((((size_t)nt * nchunks + ch) * 16 + (i * 4 + j)) * 4 + c / 2) * cbp + cb / 2) * 16 + t) * 4 +
+                          (cb % 2) * 2 + c % 2] = (float)val;
+                    }
+            }
+        if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, u.size() * sizeof(float)));
+        DODT_HIP_CHECK(hipMemcpyAsync(ln->d_w, u.data(), u.size() * sizeof(float),
+                                      hipMemcpyHostToDevice, s));
+        DODT_HIP_CHECK(hipStreamSynchronize(s));
+        continue;
+    }
     // fp32 kernels: floats; bf16 MFMA kernels: bf16 pairs packed in the same array (half of it)
     std::vector<float> blocked((size_t)9 * l.Cin * l.Cout, 0.0f);
     uint16_t* blocked16 = reinterpret_cast<uint16_t*>(blocked.data());

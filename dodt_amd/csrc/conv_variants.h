@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "conv_kernels.h"
+#include "wino_kernels.h"
 
 namespace dodt {
 
@@ -17,6 +18,7 @@ struct KernelVariant {
     bool tail_only = false;  // quarter-size tiles: never a layer's main variant
     bool bf16 = false;       // CB16 bf16 activations (first-layer kernels: bf16 OUTPUT)
     int parts = 1;           // 2: split mode, every map is a hi + lo pair of bf16 maps
+    bool wino = false;       // Winograd F(2x2,3x3) kernel (wino_kernels.h): 16 weight points, not 9 taps
 };
 
 inline KernelVariant tail_only(KernelVariant v) {
@@ -45,6 +47,26 @@ struct Inst {
                         Cfg::kLdsBytes, per_cu, &launch, &prepare};
         v.bf16 = BF16;
         v.parts = PARTS;
+        return v;
+    }
+};
+
+template <int TB, int CB>
+struct InstWino {
+    using Cfg = WinoCfg<TB, CB>;
+    static_assert(Cfg::kLdsBytes <= 160 * 1024, "variant does not fit the LDS");
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL((wino3x3_f32_kernel<TB, CB>), grid, dim3(256), Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<TB, CB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        // TW, MTB (unused), WM, WN, BN, CK, deconv, small_cin, TH, lds, blocks_per_cu
+        KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, kCK, false, false, Cfg::TH, Cfg::kLdsBytes,
+                        Cfg::kPipe ? 1 : 2, &launch, &prepare};
+        v.wino = true;
         return v;
     }
 };

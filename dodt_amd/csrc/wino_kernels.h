@@ -1,0 +1,482 @@
+// 3x3 stride-1 convolution in fp32 by Winograd F(2x2, 3x3) on the fp32 MFMA of gfx950.
+//
+// Why: the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 / 32x32x2) runs at the fp32 vector rate,
+// 1/16 of the bf16 rate, so an fp32 conv is bound by the NUMBER of multiplications.  The
+// minimal-filtering form computes every 2x2 block of outputs from a 4x4 block of inputs with
+// 16 multiplications per (input channel, output channel) instead of 36:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray 2016; Winograd 1980)
+// i.e. 16 independent GEMMs  M_xi[cout][tile] = sum_cin U_xi[cout][cin] V_xi[cin][tile]  over
+// the 16 points xi of the transformed domain -- 2.25x fewer MFMA cycles for the same layer.
+// Everything stays fp32 (the transforms are +-, the filter transform (x 1/2, x 1/4) runs on
+// the host in float64): results agree with the direct form to ~1e-6 of a layer's scale (the
+// per-layer bar of tests/test_gpu_conv.py is 1e-4).
+//
+// Work decomposition (one workgroup = 4 waves = one 16-column x 16*TB-row output tile of one
+// frame x BN = 16*CB output channels; TB * CB = 4):
+//   * a wave owns TB "tile blocks" (2 x 8 Winograd tiles = 4 x 16 output pixels each) and all
+//     BN channels: 16 points x TB x CB accumulators of v_mfma_f32_16x16x4_f32 = 256 registers.
+//     Lane l: tile t = l % 16 of the block (B operand column), k-pair g = l / 16: the MFMA's
+//     four k lanes take the chunk's input channels (2g) in one instruction and (2g + 1) in the
+//     next, so every operand is ONE 8-byte LDS read (ds_read_b64) per two MFMAs.
+//   * K is walked in chunks of 8 input channels = one CB8 plane.  Per chunk the halo'd input
+//     patch and the chunk's transformed weights [xi][h][n][4] are copied global -> LDS by
+//     global_load_lds_dwordx4 (no staging registers, no ds_write pass; out-of-image pixels read
+//     a zero page), double buffered: chunk k+1 lands while chunk k is computed, one barrier
+//     per chunk.  The chunk sequence runs across work items (persistent workgroups).
+//   * per chunk a lane reads its tile's 4x4 pixels (16 ds_read_b64), applies B^T d B (64 VALU
+//     adds, in the shadow of the other tile block's MFMAs), then issues 32 MFMAs per tile block
+//     and channel block pair.
+//   * epilogue: A^T M A per lane (it holds all 16 points of its tile and 4 consecutive output
+//     channels per channel block), batch-norm scale/shift + ReLU, 16-byte stores into the CB8
+//     (or NHWC) output.  A lane's 2x2 outputs are exactly one window of a following 2x2 max
+//     pool, so the fused pool is a max of four registers; the 1x1 bottleneck of the last
+//     layer is a dot over the lane's channels + two cross-lane adds.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "conv_kernels.h"
+
+namespace dodt {
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+template <int TB, int CB>
+struct WinoCfg {
+    static_assert(TB * CB == 4 || TB * CB == 2, "256 or 128 accumulator registers per wave");
+    // 256 accumulator registers: one wave per SIMD, the step is software-pipelined inside the
+    // wave (kPipe).  128: two workgroups per CU, the partner wave on the SIMD fills the gaps, the
+    // step is the plain sequence copies -> input transform -> MFMAs.
+    static constexpr bool kPipe = TB * CB == 4;
+    static constexpr int TW = 16;            // output columns of a workgroup tile
+    static constexpr int TH = 16 * TB;       // output rows (4 waves x TB tile blocks x 4 rows)
+    static constexpr int BN = 16 * CB;       // output channels of a workgroup tile
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    // LDS patch image: pixel (py, px) lives in 32-byte cell py * kPitch + px + ((py >> 1) & 1),
+    // its two 16-byte halves swapped when (px >> 3) & 1.  With that placement the 16 lanes
+    // that one LDS cycle of a ds_read_b64 serves (2 tile rows x 8 tile columns, pixels two
+    // apart) fall into 16 different 16-byte bank columns for every tap (r, c) of the 4x4 input
+    // tile.  The image is filled by LDS-DMA, which writes lane-linear: the permutation is
+    // applied to the SOURCE address of each 16-byte slot.
+    static constexpr int kPitch = PW + 1;
+    static constexpr int kPatchSlots = (PH * kPitch + 1) * 2;         // 16-byte slots
+    static constexpr int kPatchInstr = (kPatchSlots + 63) / 64;       // wave-level copies
+    static constexpr int kPatchFloats = kPatchInstr * 64 * 4;
+    static constexpr int kWFloats = 16 * 8 * BN;   // [xi][g][cb pair][t][cb & 1][k]: 16 B per lane
+    static constexpr int kWInstr = kWFloats / 256;
+    static constexpr int kBufFloats = kPatchFloats + kWFloats;
+    static constexpr int kLdsBytes = 2 * kBufFloats * 4 + 16 + 1024;   // + control word + dummy copy slot
+    static constexpr int kInstr = kPatchInstr + kWInstr;              // copies per chunk
+    static constexpr int kPerWave = (kInstr + 3) / 4;
+    static constexpr int kPatchPerWave = (kPatchInstr + 3) / 4;
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// 16 bytes per lane global -> LDS through a raw buffer descriptor: the LDS destination is
+// lds_base + lane * 16 (wave-uniform base), the source rsrc.base + soffset + voffset; a voffset
+// beyond the descriptor's size reads zeros (that is the conv's zero padding: no zero page,
+// no per-lane pointer select).
+// Issued as inline asm on purpose: hipcc treats the builtin form as an LDS store that every
+// later ds_read may alias and drains it (s_waitcnt vmcnt) in front of the next LDS read, which
+// would serialise the prefetch of chunk k+1 with the compute of chunk k.  The kernel waits for
+// its copies itself (vmcnt(0) ahead of the barrier that publishes the buffer).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (V#) over [base, base + bytes): stride 0, 32-bit raw format word
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff);
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void blds16(i32x4_t rsrc, int voffset, int soffset, float* lds_base) {
+    const unsigned lds_addr = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base);
+    soffset = __builtin_amdgcn_readfirstlane(soffset);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffset), "s"(rsrc), "s"(soffset), "s"(lds_addr)
+        : "memory");
+}
+constexpr int kOob = (int)0x80000000;   // voffset of an out-of-image pixel
+
+template <int TB, int CB>
+__global__ void __launch_bounds__(256, (TB * CB == 4 ? 1 : 2))
+wino3x3_f32_kernel(const ConvArgs a) {
+    using Cfg = WinoCfg<TB, CB>;
+    constexpr int BN = Cfg::BN, PW = Cfg::PW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* s_ctrl = reinterpret_cast<int*>(smem + 2 * Cfg::kBufFloats);   // behind the four images
+    float* const sDummy = smem + 2 * Cfg::kBufFloats + 4;   // 1 KB: target of a wave's surplus copy
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: addresses, branches
+    const int t = lane & 15, g = lane >> 4;
+    const int nchunks = a.Cin / 8;
+    const int in_plane = a.H * a.W * 8;
+
+    struct Item { int frame, ntile, ty0, tx0; };
+    auto decode = [&](int it) {
+        const int4 v = a.items[__builtin_amdgcn_readfirstlane(it)];
+        return Item{v.x, v.y, v.z, v.w};
+    };
+
+    // ---- copy plan of this wave: patch copies j = wave, wave + 4, ... < kPatchInstr (64 LDS
+    //      slots each), weight copies likewise over kWInstr (256 floats each) -------------------
+    int p_off[Cfg::kPatchPerWave];      // byte offset inside the plane, kOob: zero padding
+    i32x4_t in_rsrc, w_rsrc;
+    const int plane_bytes = in_plane * 4;
+    auto setup_patch = [&](const Item& it) {
+#pragma unroll
+        for (int k = 0; k < Cfg::kPatchPerWave; ++k) {
+            const int j = wave + 4 * k;
+            const int s = j * 64 + lane;
+            const int q = s >> 1;                         // 32-byte cell of the LDS image
+            const int py = q / Cfg::kPitch;
+            const int px = q - py * Cfg::kPitch - ((py >> 1) & 1);
+            const int half = (s & 1) ^ ((px >> 3) & 1);   // the halves of a cell may be swapped
+            const int gy = it.ty0 - 1 + py, gx = it.tx0 - 1 + px;
+            const bool ok = j < Cfg::kPatchInstr && py < Cfg::PH && px >= 0 && px < PW &&
+                            gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            p_off[k] = ok ? ((gy * a.W + gx) * 8 + half * 4) * 4 : kOob;
+        }
+        const float* in_item = a.in + (size_t)it.frame * a.in_frame_stride +
+                               (size_t)(a.in_coff / 8) * in_plane;
+        in_rsrc = make_rsrc(in_item, (unsigned)(nchunks * plane_bytes));
+    };
+    auto setup_w = [&](const Item& it) {
+        const float* w_item = a.w + (size_t)it.ntile * nchunks * Cfg::kWFloats;
+        w_rsrc = make_rsrc(w_item, (unsigned)(nchunks * Cfg::kWFloats * 4));
+    };
+    // LDS: two patch images, two weight images
+    float* const sPB = smem;
+    float* const sWB = smem + 2 * Cfg::kPatchFloats;
+    // copy number n of this wave for the step: n < kPatchPerWave -> patch piece of chunk pch
+    // into patch image pb; else weight piece of chunk wch into weight image wb
+    int pit = 0, pch = 0, wit = 0, wch = 0;       // copy cursors (item, chunk)
+    // Branch-free (the main loop's slices must stay single basic blocks for the scheduler): a
+    // copy that does not exist for this wave goes, with an out-of-range offset (zeros), to a
+    // dummy slot; a cursor beyond the last item has an empty descriptor.
+    auto copy_n = [&](int n, int pb, int wb) {
+        if (n < Cfg::kPatchPerWave) {            // compile-time
+            const int j = wave + 4 * n;
+            const bool real = j < Cfg::kPatchInstr;
+            float* dst = real ? sPB + pb * Cfg::kPatchFloats + j * 256 : sDummy;
+            blds16(in_rsrc, p_off[n], pch * plane_bytes, dst);
+        } else {
+            const int j = wave + 4 * (n - Cfg::kPatchPerWave);
+            const bool real = j < Cfg::kWInstr;
+            float* dst = real ? sWB + wb * Cfg::kWFloats + j * 256 : sDummy;
+            blds16(w_rsrc, real ? lane * 16 : kOob, wch * (Cfg::kWFloats * 4) + j * 1024, dst);
+        }
+    };
+    constexpr int kCopies = Cfg::kPatchPerWave + (Cfg::kWInstr + 3) / 4;
+
+    int comp_item = blockIdx.x;
+    if (comp_item >= a.n_items) return;
+    int q0 = a.n_items;                          // successor of comp_item (fetched in its step 0)
+    auto advance = [&](int& it, int& ch, bool patch) {
+        if (it >= a.n_items) return;
+        if (++ch == nchunks) {
+            ch = 0;
+            it = (it == comp_item) ? q0 : a.n_items;
+            if (it < a.n_items) {
+                if (patch) setup_patch(decode(it));
+                else setup_w(decode(it));
+            } else if (patch) {
+                in_rsrc[2] = 0;       // nothing left: every copy reads zeros
+            } else {
+                w_rsrc[2] = 0;
+            }
+        }
+    };
+
+    // lane constants: tile of the lane inside a tile block, weight fragment offset,
+    // float offsets of the lane's 4x4 input tile in the patch image (see WinoCfg)
+    const int tyl = t >> 3, txl = t & 7;
+    const int w_lane = (g * (CB / 2) * 16 + t) * 4;
+    int row_off[TB][4], col_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int px = 2 * txl + c;
+        col_off[c] = px * 8 + (((g >> 1) ^ ((px >> 3) & 1)) * 4) + (g & 1) * 2;
+    }
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int py = 2 * (2 * (wave * TB + tb) + tyl) + r;
+            row_off[tb][r] = (py * Cfg::kPitch + ((py >> 1) & 1)) * 8;
+        }
+
+    // input transform V = B^T d B of the lane's tile in tile block tb from patch image pb,
+    // split in the pieces the main loop spreads between its MFMAs
+    auto load_d = [&](f32x2_t (&d)[4][4], int tb, int r, int pb) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            d[r][c] = *reinterpret_cast<const f32x2_t*>(sPB + pb * Cfg::kPatchFloats +
+                                                          row_off[tb][r] + col_off[c]);
+    };
+    auto rows_d = [&](f32x2_t (&d)[4][4], int c) {
+        const f32x2_t t0 = d[0][c] - d[2][c], t1 = d[1][c] + d[2][c];
+        const f32x2_t t2 = d[2][c] - d[1][c], t3 = d[1][c] - d[3][c];
+        d[0][c] = t0; d[1][c] = t1; d[2][c] = t2; d[3][c] = t3;
+    };
+    auto cols_d = [&](const f32x2_t (&d)[4][4], f32x2_t (&v)[16], int i) {
+        v[i * 4 + 0] = d[i][0] - d[i][2];
+        v[i * 4 + 1] = d[i][1] + d[i][2];
+        v[i * 4 + 2] = d[i][2] - d[i][1];
+        v[i * 4 + 3] = d[i][1] - d[i][3];
+    };
+
+    // ---- prologue: patch(0), W(0) [, patch(1); V(0)] ---------------------------------------------
+    pit = wit = comp_item;
+    setup_patch(decode(pit));
+    setup_w(decode(wit));
+#pragma unroll
+    for (int n = 0; n < Cfg::kPatchPerWave; ++n) copy_n(n, 0, 0);
+    advance(pit, pch, true);
+#pragma unroll
+    for (int n = Cfg::kPatchPerWave; n < kCopies; ++n) copy_n(n, 0, 0);
+    advance(wit, wch, false);
+    if constexpr (Cfg::kPipe) {
+#pragma unroll
+        for (int n = 0; n < Cfg::kPatchPerWave; ++n) copy_n(n, 1, 0);
+        advance(pit, pch, true);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    f32x2_t va[TB][16], vb[Cfg::kPipe ? TB : 1][16];
+    if constexpr (Cfg::kPipe) {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            f32x2_t d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load_d(d, tb, r, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rows_d(d, c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cols_d(d, va[tb], i);
+        }
+        __syncthreads();      // patch image 0 is free for patch(2)
+    }
+
+    // One step = the MFMAs of chunk k (V from registers, weights from weight image k & 1) and,
+    // spread between them: the copies of W(k+1) -> weight image (k+1) & 1 and patch(k+2) ->
+    // patch image k & 1, and the input transform of chunk k+1 from patch image (k+1) & 1.
+    // PAR = k & 1 (the chunk loop is unrolled by two so that images and V sets are static).
+    auto step = [&](auto par, f32x4 (&acc)[TB][CB][16], auto& vcur, auto& vnext, int comp_ch) {
+        constexpr int PAR = decltype(par)::value;
+        if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+        const float* sW = sWB + PAR * Cfg::kWFloats + w_lane;
+        f32x2_t d[4][4];
+        if constexpr (!Cfg::kPipe) {
+            // plain step: copies of chunk k+1 (both images PAR ^ 1), then per tile block the
+            // input transform of chunk k and its MFMAs
+#pragma unroll
+            for (int n = 0; n < kCopies; ++n) copy_n(n, PAR ^ 1, PAR ^ 1);
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) load_d(d, tb, r, PAR);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rows_d(d, c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cols_d(d, vnext[0], i);
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    f32x4 wq[CB / 2];
+#pragma unroll
+                    for (int cp = 0; cp < CB / 2; ++cp)
+                        wq[cp] = *reinterpret_cast<const f32x4*>(sW + (x * 4 * (CB / 2) + cp) * 64);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb)
+                            acc[tb][cb][x] = mfma16(wq[cb >> 1][(cb & 1) * 2 + s2], vnext[0][x][s2],
+                                                    acc[tb][cb][x]);
+                }
+            }
+        } else {
+        // weight fragments are read one slice ahead of the MFMAs that use them (the slices are
+        // pinned by scheduling barriers, so nothing else prefetches them)
+        f32x4 w[2][CB / 2];
+#pragma unroll
+        for (int cp = 0; cp < CB / 2; ++cp)
+            w[0][cp] = *reinterpret_cast<const f32x4*>(sW + cp * 64);
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int sl = tb * 16 + x;                       // slice number, 0 .. 16 TB - 1
+                const int wc = sl & 1, wn = wc ^ 1;
+                if (sl + 1 < 16 * TB) {
+                    const int xn = (x + 1) & 15;
+#pragma unroll
+                    for (int cp = 0; cp < CB / 2; ++cp)
+                        w[wn][cp] = *reinterpret_cast<const f32x4*>(
+                            sW + (xn * 4 * (CB / 2) + cp) * 64);
+                }
+                // transform of chunk k+1, tile block tb: loads in slices 0..3, rows 5..8,
+                // columns 10..13 of this tile block's 16 slices (issued ahead of the MFMAs of
+                // the slice, in whose shadow they run)
+                if (x <= 3) load_d(d, tb, x, PAR ^ 1);
+                if (x >= 5 && x <= 8) rows_d(d, x - 5);
+                if (x >= 10 && x <= 13) cols_d(d, vnext[tb], x - 10);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[tb][cb][x] = mfma16(w[wc][cb >> 1][(cb & 1) * 2 + s2],
+                                                vcur[tb][x][s2], acc[tb][cb][x]);
+                if (sl < kCopies) copy_n(sl, PAR, PAR ^ 1);       // patch(k+2) -> PAR, W(k+1) -> PAR^1
+                // One wave per SIMD issues in order: whatever follows a burst of MFMAs waits for
+                // the whole burst.  Interleave: after every MFMA (32 cycles in the matrix pipe)
+                // two vector instructions and one LDS read of the slice's side work.
+#pragma unroll
+                for (int i = 0; i < 2 * CB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        }
+        // the copies issued in this step have landed (they are waited for ahead of an epilogue's
+        // stores, which share the vmcnt counter); then one barrier per chunk
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+        if (comp_ch == 0) q0 = s_ctrl[0];
+        advance(pit, pch, true);
+        advance(wit, wch, false);
+    };
+
+    while (comp_item < a.n_items) {
+        f32x4 acc[TB][CB][16];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[tb][cb][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int comp_ch = 0; comp_ch < nchunks; comp_ch += 2) {     // Cin / 8 is even
+            if constexpr (Cfg::kPipe) {
+                step(std::integral_constant<int, 0>{}, acc, va, vb, comp_ch);
+                step(std::integral_constant<int, 1>{}, acc, vb, va, comp_ch + 1);
+            } else {      // (V lives only inside a step: `va` is scratch for it)
+                step(std::integral_constant<int, 0>{}, acc, vb, va, comp_ch);
+                step(std::integral_constant<int, 1>{}, acc, vb, va, comp_ch + 1);
+            }
+        }
+
+        // ---- epilogue: Y = A^T M A, batch-norm + ReLU, stores (they drain under the next
+        //      item's first chunk) ----------------------------------------------------------------
+        {
+            const Item it = decode(comp_item);
+            float* out = a.out + (size_t)it.frame * a.out_frame_stride;
+            const int out_rows = a.H - a.out_y0;
+            const long long plane = (long long)out_rows * a.W * 8;
+            const bool pool = a.pool_out != nullptr;
+            const long long pplane = (long long)(a.H >> 1) * (a.W >> 1) * 8;
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int oy0 = it.ty0 + 2 * (2 * (wave * TB + tb) + tyl);
+                const int ox0 = it.tx0 + 2 * txl;
+                float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const int c0 = it.ntile * BN + cb * 16 + 4 * g;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
+                    f32x4 y[4];       // outputs (0,0) (0,1) (1,0) (1,1), 4 channels each
+                    {
+                        const f32x4* m = acc[tb][cb];
+                        f32x4 z[4][2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            z[i][0] = (m[i * 4 + 0] + m[i * 4 + 1]) + m[i * 4 + 2];
+                            z[i][1] = (m[i * 4 + 1] - m[i * 4 + 2]) - m[i * 4 + 3];
+                        }
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            y[0 + b] = (z[0][b] + z[1][b]) + z[2][b];
+                            y[2 + b] = (z[1][b] - z[2][b]) - z[3][b];
+                        }
+                    }
+                    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float tv = y[q][k] * sc[k] + sh[k];
+                            y[q][k] = a.relu ? fmaxf(tv, 0.0f) : tv;
+                        }
+                        const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
+                        const bool ok = oy < a.H && ox < a.W && oy >= a.out_y0;
+                        if (ok) {
+                            float* dst;
+                            if (a.out_nhwc)
+                                dst = out + ((size_t)(oy - a.out_y0) * a.W + ox) * a.out_ld +
+                                      a.out_coff + c0;
+                            else
+                                dst = out + (size_t)((a.out_coff + c0) >> 3) * plane +
+                                      ((size_t)(oy - a.out_y0) * a.W + ox) * 8 + (c0 & 7);
+                            *reinterpret_cast<f32x4*>(dst) = y[q];
+                        }
+                        if (q == 0) mx = y[0];
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], y[q][k]);
+                        }
+                        if (a.bneck_w) {
+                            const f32x4 bw = *reinterpret_cast<const f32x4*>(a.bneck_w + c0);
+                            dot[q] += ((y[q][0] * bw[0] + y[q][1] * bw[1]) + y[q][2] * bw[2]) +
+                                      y[q][3] * bw[3];
+                        }
+                    }
+                    // a lane's 2x2 outputs = one window of the following VALID 2x2 max pool
+                    if (pool && oy0 + 1 < a.H && ox0 + 1 < a.W) {
+                        float* dst = a.pool_out + (size_t)it.frame * a.pool_frame_stride +
+                                     (size_t)(c0 >> 3) * pplane +
+                                     ((size_t)(oy0 >> 1) * (a.W >> 1) + (ox0 >> 1)) * 8 + (c0 & 7);
+                        *reinterpret_cast<f32x4*>(dst) = mx;
+                    }
+                    // keep the channel blocks apart: interleaved, their 4 x 64 accumulator
+                    // registers would all be live in VGPRs at once
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (a.bneck_w) {    // the other channels of these pixels live in lanes l ^ 16, ^ 32
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float s = dot[q];
+                        s += __shfl_xor(s, 16, 64);
+                        s += __shfl_xor(s, 32, 64);
+                        const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
+                        if (g == 0 && oy < a.H && ox < a.W && oy >= a.out_y0)
+                            a.bneck_out[(size_t)it.frame * a.bneck_frame_stride +
+                                        (size_t)(oy - a.out_y0) * a.W + ox] =
+                                fmaxf(s * a.bneck_scale + a.bneck_shift, 0.0f);
+                    }
+                }
+            }
+        }
+        comp_item = q0;
+    }
+}
+
+}  // namespace dodt
