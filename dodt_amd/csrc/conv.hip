@@ -81,10 +81,11 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     int best = -1;
     double best_cost = 1e300;
     // fp32 3x3 stride-1 convs with >= 4 chunks of input channels run as Winograd F(2x2,3x3)
-    // (2.25x fewer fp32 MFMA cycles); DODT_CONV_WINO=0 keeps the direct kernels
-    static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 0;
-    // 1: the 256-accumulator variants (one workgroup per CU), 2: the 128-accumulator variant
-    // (two workgroups per CU)
+    // (2.25x fewer fp32 MFMA cycles).  DODT_CONV_WINO: 2 (default) = the 128-accumulator variant,
+    // two workgroups per CU (both stacks 3.0 ms against 4.8 ms for the direct kernels);
+    // 1 = the 256-accumulator variants, one workgroup per CU (no faster than direct: a lone
+    // wave per SIMD issues in order and nothing hides behind its MFMA bursts); 0 = direct.
+    static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 2;
     if (wino_mode > 0 && !deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].wino || Cout % vs[i].BN != 0) continue;
