@@ -336,7 +336,8 @@ def main():
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
                    step_ms=step_ms, host_ms=host_ms,
                    both_ms=both_ms,
-                   flops=pipe.flops_per_step(), head_gflop=pipe.head_flops_per_step() / 1e9,
+                   flops=pipe.flops_per_step(), mfma_flops=pipe.mfma_flops_per_step(),
+                   head_gflop=pipe.head_flops_per_step() / 1e9,
                    conv_bytes=pipe.conv_bytes_per_step(),
                    anchors=list(pipe.last_anchor_counts), steps=steps)
         pipe.close()
@@ -392,15 +393,16 @@ def main():
     # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
     # figure comes from the rocprofv3 --pmc passes over this same command (profiles/)
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, 'profiles', {'f32': 'r1_conv_traffic.json',
-                                         'f32s': 'r1f32s_conv_traffic.json',
-                                         'bf16': 'r1bf16_conv_traffic.json'}[args.conv_dtype])
+    tj = os.path.join(ROOT, 'profiles', {'f32': 'r2_conv_traffic.json',
+                                         'f32s': 'r2f32s_conv_traffic.json',
+                                         'bf16': 'r2bf16_conv_traffic.json'}[args.conv_dtype])
     if os.path.exists(tj):
         t = json.load(open(tj))
         traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
         traffic_src = t['source']
     common = dict(traffic=traffic, traffic_unit='bytes/launch', traffic_source=traffic_src,
-                  kernel='conv3x3_mfma_kernel (30 launches per step) + 2 first-layer launches',
+                  kernel='wino3x3_f32_kernel (24 launches per step) + conv3x3_mfma_kernel (6 transposed convs) '
+                         '+ 2 first-layer launches',
                   launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
                   algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
                   launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),
@@ -410,9 +412,18 @@ def main():
                            'timed region' % reps)
     if args.conv_dtype == 'f32':
         # fp32 MFMA: 157.3 TFLOP/s dense (MI355X_MICROARCH.md chip table); every layer is
-        # MFMA-bound at fp32
+        # MFMA-bound at fp32.  `achieved` prices the ALGORITHMIC FLOPs (2 M N K of the direct
+        # form); the 3x3 stride-1 layers run as Winograd F(2x2,3x3), which executes
+        # 16/36 of them: what the matrix pipe really does is given beside it.
+        executed = m['mfma_flops'] / (conv_ms * 1e-3) / 1e12
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=157.3, unit='TFLOP/s',
-                        frac=round(achieved / 157.3, 4), **common)
+                        frac=round(achieved / 157.3, 4),
+                        executed_gflop=round(m['mfma_flops'] / 1e9, 2),
+                        executed_tflops=round(executed, 2),
+                        executed_frac=round(executed / 157.3, 4),
+                        algorithm='Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 for the 3x3 '
+                                  'stride-1 layers (fp32 throughout), direct implicit GEMM for '
+                                  'the first layer and the transposed convs', **common)
     elif args.conv_dtype == 'f32s':
         # split mode: three bf16 MFMAs per product term -> 3x the algorithmic FLOPs on the
         # bf16 pipe (2.5 PFLOP/s dense); the fp32-equivalent rate is given beside it

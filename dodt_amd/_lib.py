@@ -102,6 +102,7 @@ SIGNATURES = {
                                             C.POINTER(_i)]),
     'dodt_extractor_output_shape': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'dodt_extractor_flops': (_d, [_vp]),
+    'dodt_extractor_mfma_flops': (_d, [_vp]),
     'dodt_extractor_bytes': (_d, [_vp]),
     'dodt_crop_and_resize': (_i, [_vp, _pf, _i, _i, _i, _pf, _i, _pi32, _i, _i,
                                   _pf]),

@@ -106,6 +106,10 @@ class _VggPyr(object):
     def flops(self):
         return self._ctx.lib.dodt_extractor_flops(self._handle)
 
+    def mfma_flops(self):
+        """FLOPs the matrix pipe executes (Winograd layers: 16/36 of the direct count)."""
+        return self._ctx.lib.dodt_extractor_mfma_flops(self._handle)
+
     def bytes(self):
         """Algorithmic HBM bytes of one forward."""
         return self._ctx.lib.dodt_extractor_bytes(self._handle)

@@ -938,6 +938,18 @@ double dodt_extractor_bytes(const dodt_extractor* ex) {
     return b;
 }
 
+double dodt_extractor_mfma_flops(const dodt_extractor* ex) {
+    if (!ex) return 0.0;
+    // FLOPs the matrix pipe executes: Winograd F(2x2,3x3) layers multiply 16 times per 2x2
+    // outputs and channel pair instead of 36
+    double f = 0.0;
+    for (const Layer& l : ex->layers) {
+        const double direct = 2.0 * l.H * l.W * (double)l.Cout * 9.0 * l.real_cin * ex->batch;
+        f += variants()[l.main.variant].wino ? direct * 16.0 / 36.0 : direct;
+    }
+    return f;
+}
+
 double dodt_extractor_flops(const dodt_extractor* ex) {
     if (!ex) return 0.0;
     double f = 0.0;  // 2*M*N*K per layer; transposed convs counted on input pixels

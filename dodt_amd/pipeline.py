@@ -438,6 +438,10 @@ class FramePairPipeline(object):
         """Conv stacks only (the roofline kernel); see head_flops_per_step."""
         return self.bev_net.flops() + self.img_net.flops()
 
+    def mfma_flops_per_step(self):
+        """FLOPs the matrix pipe executes for the two conv stacks (Winograd layers count 16/36)."""
+        return self.bev_net.mfma_flops() + self.img_net.mfma_flops()
+
     def conv_bytes_per_step(self):
         """Algorithmic HBM bytes of the two conv stacks per step."""
         return self.bev_net.bytes() + self.img_net.bytes()

@@ -245,8 +245,13 @@ int dodt_extractor_output_shape(const dodt_extractor* ex, int* h, int* w, int* c
  * (batch, h, w, c) float32 tensor to host memory `dst` (NULL to query shape). */
 int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* dst,
                                    int* h, int* w, int* c);
-/* FLOPs of one forward call (2*M*N*K summed over conv layers, all frames). */
+/* FLOPs of one forward call (2*M*N*K summed over conv layers, all frames): the ALGORITHMIC
+ * count of the direct form, whatever kernel computes a layer. */
 double dodt_extractor_flops(const dodt_extractor* ex);
+/* FLOPs the matrix pipe executes for one forward: the fp32 3x3 stride-1 layers run as Winograd
+ * F(2x2,3x3) (16 multiplications per 2x2 outputs where the direct form needs 36; fp32 throughout,
+ * within 1e-6 of the direct result) unless DODT_CONV_WINO=0 is set in the environment. */
+double dodt_extractor_mfma_flops(const dodt_extractor* ex);
 /* Algorithmic HBM bytes of one forward (each map and the weights read / written once). */
 double dodt_extractor_bytes(const dodt_extractor* ex);
 

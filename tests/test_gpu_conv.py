@@ -122,3 +122,43 @@ def test_extractor_errors():
         ex2.build(np.zeros((1, 28, 40, 6), np.float32))      # weights not set
     with pytest.raises(NotImplementedError):
         ex2.build(np.zeros((1, 28, 40, 6), np.float32), is_training=True)
+
+
+@pytest.mark.parametrize('mode', ['0', '1'])
+def test_other_fp32_conv_paths_match_oracle(mode):
+    """The default fp32 path of the 3x3 stride-1 layers is the Winograd F(2x2,3x3) kernel with
+    128 accumulators (DODT_CONV_WINO=2, what every other test in this file runs).  The direct
+    implicit-GEMM kernels (0) and the 256-accumulator Winograd variants (1) stay selectable
+    through the environment, which the library reads once per process: they are checked in a
+    child process against the same oracle at the same 1e-4 bar."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from dodt_amd import synth
+from dodt_amd.core.feature_extractors.vgg_pyramid import BevVggPyr
+from oracle import extractors as oext
+rng = np.random.default_rng(60 * 96)
+x = rng.uniform(0, 1, size=(2, 60, 96, 6)).astype(np.float32)
+x[x < 0.7] = 0
+params = synth.pyramid_params(6, seed=42)
+ex = BevVggPyr(); ex.load_params(params)
+feat, ends = ex.build(x, with_bottleneck=True)
+worst = 0.0
+for f in range(2):
+    c = {}
+    want = oext.vgg_pyramid(x[f], params, pad_top=4, collect=c)
+    for name in synth.PYRAMID_LAYERS[:-1]:
+        got = ex.activation(name)[f]
+        worst = max(worst, np.abs(got - c[name]).max() / (np.abs(c[name]).max() + 1e-12))
+    worst = max(worst, np.abs(feat[f] - want).max() / (np.abs(want).max() + 1e-12))
+print('WORST %%.3e' %% worst)
+assert worst < 1e-4
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DODT_CONV_WINO=mode)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'WORST' in r.stdout

@@ -9,6 +9,11 @@ import os
 import shutil
 import sys
 
+
+def is_conv(name):
+    return 'conv3x3' in name or 'wino3x3' in name
+
+
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, 'profiles')
@@ -32,16 +37,16 @@ for r in rows[:24]:
         r['Name'][:70].replace('|', '/'), r['Calls'], float(r['TotalDurationNs']) / 1e6,
         float(r['AverageNs']) / 1e3, r['Percentage']))
 for r in rows:
-    if 'conv3x3' in r['Name']:
+    if is_conv(r['Name']):
         conv_ns += float(r['TotalDurationNs'])
         conv_calls += int(r['Calls'])
-lines += ['', 'conv3x3_* kernels: %d launches, %.2f ms total, average launch %.1f us '
+lines += ['', 'conv kernels (wino3x3_* + conv3x3_*): %d launches, %.2f ms total, average launch %.1f us '
           '(the two nets overlap on two streams during the timed steps, which stretches '
           'each kernel)' % (conv_calls, conv_ns / 1e6, conv_ns / 1e3 / max(conv_calls, 1))]
 # the roofline section of bench.py: the LAST reps forwards of each net, run alone
 trace = one('%s_stats/**/*kernel_trace.csv' % tag)
 if trace:
-    tr = [r for r in csv.DictReader(open(trace)) if 'conv3x3' in r['Kernel_Name']]
+    tr = [r for r in csv.DictReader(open(trace)) if is_conv(r['Kernel_Name'])]
     tr.sort(key=lambda r: int(r['Start_Timestamp']))
     reps = 10
     # bench.py ends with `reps` forwards of each net alone, then `reps` forwards side by side
@@ -71,7 +76,7 @@ pm = one('%s_pmc_mfma/**/*counter_collection.csv' % tag)
 if pm:
     agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for e in counters(pm):
-        if 'conv3x3' not in e['name']:
+        if not is_conv(e['name']):
             continue
         key = e['name'].split('(')[0][-60:]
         agg[key][0] += e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0)
@@ -84,7 +89,7 @@ if pm:
         lines.append('| %s | %d | %.3f |' % (k, n, b / max(a, 1)))
         tb += b
         ta += a
-    lines.append('| all conv3x3 kernels | | %.3f |' % (tb / max(ta, 1)))
+    lines.append('| all conv kernels | | %.3f |' % (tb / max(ta, 1)))
 traffic = {}
 for kind, ctr, corr in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.0)):
     pth = one('%s_pmc_%s/**/*counter_collection.csv' % (tag, kind))
@@ -92,7 +97,7 @@ for kind, ctr, corr in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE', 1.
         continue
     tot = n = 0
     for e in counters(pth):
-        if 'conv3x3' in e['name']:
+        if is_conv(e['name']):
             tot += e.get(ctr, 0) * 1024.0 * corr     # KB units; gfx950: FETCH_SIZE reads 1/2
             n += 1
     traffic[kind] = (tot, n)
@@ -104,7 +109,7 @@ if traffic:
             k, tot / 1e6, n, tot / 1e6 / max(n, 1)))
 if len(traffic) == 2:
     per = {k: tot / max(n, 1) for k, (tot, n) in traffic.items()}
-    json.dump({'kernel': 'conv3x3_* (all conv launches of the timed steps)',
+    json.dump({'kernel': 'wino3x3_* + conv3x3_* (all conv launches of the timed steps)',
                'fetch_bytes_per_launch': per['fetch'], 'write_bytes_per_launch': per['write'],
                'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 '
                          '(gfx950 correction), profiles/%s_summary.md' % tag},
