@@ -94,9 +94,20 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         }
         if (best >= 0) return best;
     }
+    // DODT_CONV_BF16_DMA=1: bf16 3x3 stride-1 layers on the LDS-DMA staged kernel
+    // (conv_bf16_dma.h) instead of the template's bf16 instantiation.  Measured at parity
+    // (both stacks 1.24 ms against 1.27 ms): the bf16 layers are bound by the global -> LDS fill
+    // rate either way, so it is not the default.
+    static const bool bf16_dma = getenv("DODT_CONV_BF16_DMA") && atoi(getenv("DODT_CONV_BF16_DMA")) != 0;
+    if (bf16_dma && bf16 && parts == 1 && !deconv && Cin >= 32 && Cin % 32 == 0) {
+        for (size_t i = 0; i < vs.size(); ++i)
+            if (vs[i].dma && Cout % vs[i].BN == 0 && (best < 0 || vs[i].BN > vs[best].BN))
+                best = (int)i;
+        if (best >= 0) return best;
+    }
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
-        if (v.wino) continue;
+        if (v.wino || v.dma) continue;
         if (v.deconv != deconv || v.small_cin != small || v.tail_only || v.bf16 != bf16 ||
             v.parts != parts || Cout % v.BN != 0)
             continue;
@@ -430,7 +441,7 @@ void plan_layer(Layer& l, int batch, int num_cus, bool allow_tail, std::vector<i
                 for (int x = 0; x < tx; ++x) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
     l.main.variant = l.variant;
     l.tail.variant = -1;
-    if (v.small_cin || v.wino) return;
+    if (v.small_cin || v.wino || v.dma) return;
     static const bool no_tail = getenv("DODT_CONV_NO_TAIL") != nullptr;
     const int n = (int)main_items.size();
     const int G = num_cus * v.blocks_per_cu;

@@ -27,6 +27,9 @@ std::vector<KernelVariant> bf16_variants() {
         Inst<16, 4, 4, 1, 64, true, true>::variant(),
         Inst<8, 4, 4, 1, 64, true, true>::variant(),
         Inst<4, 4, 4, 1, 64, true, true>::variant(),
+        // round 2: LDS-DMA staged 3x3 stride-1 kernels, 16 x 32 px x 64 / 32 channels
+        InstBf16Dma<4, 2, 2>::variant(),
+        InstBf16Dma<4, 1, 2>::variant(),
     };
 }
 

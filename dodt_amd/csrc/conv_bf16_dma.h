@@ -1,0 +1,252 @@
+// 3x3 stride-1 convolution on the bf16 MFMA (v_mfma_f32_32x32x16_bf16) over CB16 bf16 maps --
+// round 2's kernel for the bf16 conv path (BASELINE.json configs[2]); it replaces the fp32
+// kernel template's BF16 instantiation (conv_kernels.h), whose fragment reads and register
+// staging paced the loop instead of the matrix pipe.
+//
+// At bf16 an MFMA takes 32 cycles for the work an fp32 kernel spends 4 x 64 on, so the
+// kernel is shaped by bytes, not by multiplications:
+//   * staging: the halo'd patch of a 16-channel chunk and the chunk's weights [tap][h][n][16 B]
+//     go global -> LDS by buffer_load_dwordx4 ... lds (LDS-DMA: no staging registers, no
+//     ds_write pass; out-of-image pixels are out of the descriptor's range and read zeros),
+//     double buffered, one barrier per chunk, two workgroups per CU so that one's copies and
+//     barrier hide behind the other's MFMAs.
+//   * LDS reads: a wave owns MT rows of 32 pixels and 32 NT output channels.  For one kx it
+//     reads the MT + 2 patch rows its three ky taps share (row-sliding reuse: 3 (MT + 2)
+//     instead of 9 MT pixel fragments per chunk) and 3 NT weight fragments; 9 MT NT MFMAs.
+//   * the patch image is conflict-free: a pixel cell is 32 bytes (two 16-byte k-halves); the
+//     halves of the cells with (column >> 3) & 1 are swapped -- by permuting the SOURCE address
+//     of the lane-linear LDS-DMA -- so that the 16 lanes of one ds_read_b128 group
+//     ({0-3,12-15,20-27} / {4-11,16-19,28-31}, columns 8 or 24 apart) hit 16 different bank
+//     columns for every kx.
+// The accumulator layout (weights = A operand: rows = output channels in the permuted order of
+// group_channel<true>, pixels = B operand) is the fp32 template's, so its epilogue (batch-norm
+// + ReLU, bf16 CB16 / fp32 NHWC stores, fused 2x2 max pool, fused 1x1 bottleneck) is reused
+// unchanged (store_tile / pool_tile of conv_kernels.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "conv_kernels.h"
+#include "wino_kernels.h"   // blds16, make_rsrc, kOob
+
+namespace dodt {
+
+template <int MT, int NT, int S>
+struct Bf16DmaCfg {
+    static_assert(S >= 2 && S <= 4, "ring of 2..4 chunk images");
+    static constexpr int TW = 32, TH = 4 * MT, BN = 32 * NT;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int kPatchSlots = PH * PW * 2;                 // 16-byte slots
+    static constexpr int kPatchInstr = (kPatchSlots + 63) / 64;     // 1 KB wave-level copies
+    static constexpr int kPatchFloats = kPatchInstr * 256;
+    static constexpr int kWFloats = 9 * 2 * BN * 4;                 // [tap][h][n][16 B]
+    static constexpr int kWInstr = kWFloats / 256;
+    static constexpr int kBufFloats = kPatchFloats + kWFloats;
+    static constexpr int kLdsBytes = S * kBufFloats * 4 + 16 + 1024;
+    static constexpr int kPatchPerWave = (kPatchInstr + 3) / 4;
+    static constexpr int kWPerWave = (kWInstr + 3) / 4;
+    static constexpr int kCopies = kPatchPerWave + kWPerWave;
+    static_assert(kWFloats % 256 == 0, "weight image is a whole number of 1 KB copies");
+    static_assert((S - 2) * kCopies <= 63, "vmcnt is six bits");
+    static_assert(MT % 2 == 0, "the fused pool pairs the rows of a wave");
+};
+
+template <int MT, int NT, int S>
+__global__ void __launch_bounds__(256, (S == 2 ? 2 : 1))
+conv3x3_bf16_dma_kernel(const ConvArgs a) {
+    using Cfg = Bf16DmaCfg<MT, NT, S>;
+    constexpr int BN = Cfg::BN, PW = Cfg::PW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // ring of S chunk images: [patch | weights] each
+    int* s_ctrl = reinterpret_cast<int*>(smem + S * Cfg::kBufFloats);
+    float* const sDummy = smem + S * Cfg::kBufFloats + 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = a.Cin / 16;
+    const int in_plane = a.H * a.W * 8;          // floats per CB16 plane (32 B per pixel)
+    const int plane_bytes = in_plane * 4;
+
+    struct Item { int frame, ntile, ty0, tx0; };
+    auto decode = [&](int it) {
+        const int4 v = a.items[__builtin_amdgcn_readfirstlane(it)];
+        return Item{v.x, v.y, v.z, v.w};
+    };
+
+    int p_off[Cfg::kPatchPerWave];
+    i32x4_t in_rsrc, w_rsrc;
+    auto setup = [&](const Item& it) {
+#pragma unroll
+        for (int k = 0; k < Cfg::kPatchPerWave; ++k) {
+            const int j = wave + 4 * k;
+            const int s = j * 64 + lane;
+            const int q = s >> 1;
+            const int py = q / PW, px = q - py * PW;
+            const int half = (s & 1) ^ ((px >> 3) & 1);
+            const int gy = it.ty0 - 1 + py, gx = it.tx0 - 1 + px;
+            const bool ok = j < Cfg::kPatchInstr && py < Cfg::PH && gy >= 0 && gy < a.H &&
+                            gx >= 0 && gx < a.W;
+            p_off[k] = ok ? ((gy * a.W + gx) * 8 + half * 4) * 4 : kOob;
+        }
+        const float* in_item = a.in + (size_t)it.frame * a.in_frame_stride +
+                               (size_t)(a.in_coff / 16) * in_plane;
+        in_rsrc = make_rsrc(in_item, (unsigned)(nchunks * plane_bytes));
+        const float* w_item = a.w + (size_t)it.ntile * nchunks * Cfg::kWFloats;
+        w_rsrc = make_rsrc(w_item, (unsigned)(nchunks * Cfg::kWFloats * 4));
+    };
+    // Work items known to this workgroup: k0 is being computed, k1 follows it and k2 follows k1
+    // (k2 is claimed from the atomic counter during the first step of every item, in time for
+    // the copy cursor, which runs S - 1 <= 3 chunks = at most two items ahead of the MFMAs).
+    int k0 = blockIdx.x, k1 = a.n_items, k2 = a.n_items;
+    if (k0 >= a.n_items) return;
+    if (tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+    __syncthreads();
+    k1 = s_ctrl[0];
+    __syncthreads();
+    int cslot = 0, cch = 0;
+    bool cur_live = true;            // the cursor points at a real chunk
+    auto copies = [&](int b) {
+        float* img = smem + b * Cfg::kBufFloats;
+#pragma unroll
+        for (int n = 0; n < Cfg::kPatchPerWave; ++n) {
+            const int j = wave + 4 * n;
+            const bool real = j < Cfg::kPatchInstr;
+            blds16(in_rsrc, p_off[n], cch * plane_bytes, real ? img + j * 256 : sDummy);
+        }
+#pragma unroll
+        for (int n = 0; n < Cfg::kWPerWave; ++n) {
+            const int j = wave + 4 * n;
+            const bool real = j < Cfg::kWInstr;
+            blds16(w_rsrc, real ? lane * 16 : kOob, cch * (Cfg::kWFloats * 4) + j * 1024,
+                   real ? img + Cfg::kPatchFloats + j * 256 : sDummy);
+        }
+    };
+    auto advance = [&]() {
+        if (!cur_live) return;
+        if (++cch == nchunks) {
+            cch = 0;
+            ++cslot;
+            const int nxt = cslot == 1 ? k1 : cslot == 2 ? k2 : a.n_items;
+            if (nxt < a.n_items) {
+                setup(decode(nxt));
+            } else {
+                cur_live = false;
+                in_rsrc[2] = 0;       // nothing left: the remaining copies read zeros
+                w_rsrc[2] = 0;
+            }
+        }
+    };
+
+    // lane constants: float offset of (row 0, column li + kx) with the half swap; weights
+    int col_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int c = li + kx;
+        col_off[kx] = c * 8 + ((lh ^ ((c >> 3) & 1)) * 4);
+    }
+    const int row0 = wave * MT * PW * 8;
+    const int w_lane = (lh * BN + li) * 4;
+
+    // ---- prologue: chunks 0 .. S-2 of the flat (item, chunk) sequence -----------------------
+    setup(decode(k0));
+#pragma unroll
+    for (int b = 0; b < S - 1; ++b) {
+        copies(b);
+        advance();
+    }
+    // chunk 0 has landed once all but the newest (S - 2) chunks' copies are done
+    __builtin_amdgcn_s_waitcnt(0xc07f & ~0xc00f | (((S - 2) * Cfg::kCopies) & 0xf) |
+                               ((((S - 2) * Cfg::kCopies) >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+
+    int ring = 0;                    // image of the chunk being computed
+    while (k0 < a.n_items) {
+        f32x16 acc[MT * NT];
+#pragma unroll
+        for (int k = 0; k < MT * NT; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+        for (int comp_ch = 0; comp_ch < nchunks; ++comp_ch) {
+            if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+            // copies of chunk (k + S - 1) into the image chunk k - 1 used (free since the barrier)
+            int wr = ring + S - 1;
+            if (wr >= S) wr -= S;
+            copies(wr);
+            const float* sP = smem + ring * Cfg::kBufFloats + row0;
+            const float* sW = smem + ring * Cfg::kBufFloats + Cfg::kPatchFloats + w_lane;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                f32x4 x[MT + 2];
+#pragma unroll
+                for (int r = 0; r < MT + 2; ++r)
+                    x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[kx]);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    f32x4 w[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        w[nt] = *reinterpret_cast<const f32x4*>(
+                            sW + ((ky * 3 + kx) * 2 * BN + nt * 32) * 4);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt * NT + nt] = mfma_bf16(w[nt], x[mt + ky], acc[mt * NT + nt]);
+                }
+            }
+            // the next chunk has landed once all but the newest (S - 2) chunks' copies are done
+            // (vmcnt is in issue order; an epilogue's stores are older than those copies)
+            __builtin_amdgcn_s_waitcnt(0xc07f & ~0xc00f | (((S - 2) * Cfg::kCopies) & 0xf) |
+                                       ((((S - 2) * Cfg::kCopies) >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            if (comp_ch == 0) k2 = s_ctrl[0];     // the item claimed in this step: third in line
+            advance();
+            if (++ring == S) ring = 0;
+        }
+        // ---- epilogue (as in conv3x3_mfma_kernel): BN + ReLU, stores, fused pool / bottleneck ---
+        const Item cur = decode(k0);
+        float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
+        const int out_rows = a.H - a.out_y0;
+        const long long plane = (long long)out_rows * a.W * 8;
+        const bool pool = a.pool_out != nullptr;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = cur.ty0 + wave * MT + mt;
+            const int x = cur.tx0 + li;
+            const bool ok = y < a.H && x < a.W && y >= a.out_y0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c0 = cur.ntile * BN + nt * 32;
+                if (pool)
+                    store_tile<true, true, true, false>(a, out, acc[mt * NT + nt], c0, lh,
+                                                        y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                else if (!a.out_nhwc)
+                    store_tile<false, true, true, false>(a, out, acc[mt * NT + nt], c0, lh,
+                                                         y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                else
+                    store_tile<false, true, false>(a, out, acc[mt * NT + nt], c0, lh, y - a.out_y0,
+                                                   x, a.W, plane, ok, cur.frame);
+            }
+        }
+        if (pool) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt += 2) {
+                const int y = cur.ty0 + wave * MT + mt;
+                const int x = cur.tx0 + li;
+                const bool ok = y < a.H && x < a.W;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    pool_tile<32, true, true, false>(a, acc[mt * NT + nt], acc[(mt + 1) * NT + nt],
+                                                     cur.ntile * BN + nt * 32, lh, y, x, cur.frame, ok);
+            }
+        }
+        // next item: the queue moves up, the cursor's slot with it
+        k0 = k1;
+        k1 = k2;
+        k2 = a.n_items;
+        --cslot;
+    }
+}
+
+}  // namespace dodt

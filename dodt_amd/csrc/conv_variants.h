@@ -5,6 +5,7 @@
 
 #include "conv_kernels.h"
 #include "wino_kernels.h"
+#include "conv_bf16_dma.h"
 
 namespace dodt {
 
@@ -19,6 +20,7 @@ struct KernelVariant {
     bool bf16 = false;       // CB16 bf16 activations (first-layer kernels: bf16 OUTPUT)
     int parts = 1;           // 2: split mode, every map is a hi + lo pair of bf16 maps
     bool wino = false;       // Winograd F(2x2,3x3) kernel (wino_kernels.h): 16 weight points, not 9 taps
+    bool dma = false;        // bf16 kernel with LDS-DMA staging (conv_bf16_dma.h)
 };
 
 inline KernelVariant tail_only(KernelVariant v) {
@@ -67,6 +69,28 @@ struct InstWino {
         KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, kCK, false, false, Cfg::TH, Cfg::kLdsBytes,
                         Cfg::kPipe ? 1 : 2, &launch, &prepare};
         v.wino = true;
+        return v;
+    }
+};
+
+template <int MT, int NT, int S>
+struct InstBf16Dma {
+    using Cfg = Bf16DmaCfg<MT, NT, S>;
+    static_assert(Cfg::kLdsBytes <= 160 * 1024, "variant does not fit the LDS");
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<MT, NT, S>), grid, dim3(256), Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_dma_kernel<MT, NT, S>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        int per_cu = (160 * 1024) / Cfg::kLdsBytes;
+        if (per_cu > (S == 2 ? 2 : 1)) per_cu = (S == 2 ? 2 : 1);
+        KernelVariant v{Cfg::TW, 4 * MT, 4, 1, Cfg::BN, 16, false, false, Cfg::TH, Cfg::kLdsBytes,
+                        per_cu, &launch, &prepare};
+        v.bf16 = true;
+        v.dma = true;
         return v;
     }
 };
