@@ -381,15 +381,18 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     v.launch(a, grid, ex->ctx->stream);
     DODT_LAUNCH_CHECK();
     if (a.debug & 32) {
-        int h[72];
+        int h[74];
         (void)hipStreamSynchronize(ex->ctx->stream);
         (void)hipMemcpy(h, ex->d_counters + 64 + 32, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[dodt] %s step stamps (cycles): issue | compute | wait copies | barrier | total\n",
+        fprintf(stderr, "[dodt] %s step stamps (cycles): copies | transform | MFMAs | wait copies | barrier | step\n",
                 l.name.c_str());
         for (int k = 0; k < 12; ++k)
-            fprintf(stderr, "[dodt]   step %2d: %6d %6d %6d %6d   next-top %6d\n", k, h[k * 6 + 1] - h[k * 6],
+            fprintf(stderr, "[dodt]   step %2d: %6d %6d %6d %6d %6d   next-top %6d\n", k, h[k * 6 + 1] - h[k * 6],
                     h[k * 6 + 2] - h[k * 6 + 1], h[k * 6 + 3] - h[k * 6 + 2], h[k * 6 + 4] - h[k * 6 + 3],
-                    k < 11 ? h[(k + 1) * 6] - h[k * 6] : 0);
+                    h[k * 6 + 5] - h[k * 6 + 4], k < 11 ? h[(k + 1) * 6] - h[k * 6] : 0);
+        if (h[73] != h[72])
+            fprintf(stderr, "[dodt]   steps 0..11: %d stamp ticks in %d ticks of the 100 MHz clock (%.0f MHz)\n",
+                    h[66] - h[0], h[73] - h[72], 100.0 * (h[66] - h[0]) / (h[73] - h[72]));
     }
     if (a.debug & 8) {   // diagnostic: print the in-kernel clock of this launch
         unsigned long long h[2] = {0, 0};

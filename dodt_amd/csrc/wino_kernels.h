@@ -278,6 +278,7 @@ wino3x3_f32_kernel(const ConvArgs a) {
     // spread between them: the copies of W(k+1) -> weight image (k+1) & 1 and patch(k+2) ->
     // patch image k & 1, and the input transform of chunk k+1 from patch image (k+1) & 1.
     // PAR = k & 1 (the chunk loop is unrolled by two so that images and V sets are static).
+    int k_stamp = 0;      // steps this wave has run (diagnostic stamps)
     auto step = [&](auto par, f32x4 (&acc)[TB][CB][16], auto& vcur, auto& vnext, int comp_ch) {
         constexpr int PAR = decltype(par)::value;
         if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
@@ -285,9 +286,21 @@ wino3x3_f32_kernel(const ConvArgs a) {
         f32x2_t d[4][4];
         if constexpr (!Cfg::kPipe) {
             // plain step: copies of chunk k+1 (both images PAR ^ 1), then per tile block the
-            // input transform of chunk k and its MFMAs
+            // input transform of chunk k and its MFMAs.
+            // (a.debug: diagnostic switches of tools/, 0 in production -- 2: no copies; 32:
+            //  s_memtime stamps of one wave's first 12 steps into counter_base[32..103])
+            const bool stamp = (a.debug & 32) && blockIdx.x == 1 && tid == 0 && k_stamp < 12;
+            int* stamps = a.counter_base + 32 + (k_stamp < 12 ? k_stamp : 0) * 6;
+            if (stamp) {
+                stamps[0] = (int)__builtin_amdgcn_s_memtime();
+                if (k_stamp == 0 || k_stamp == 11)    // 100 MHz reference beside it, to calibrate
+                    a.counter_base[32 + 72 + (k_stamp != 0)] = (int)__builtin_amdgcn_s_memrealtime();
+            }
+            if (!(a.debug & 2)) {
 #pragma unroll
-            for (int n = 0; n < kCopies; ++n) copy_n(n, PAR ^ 1, PAR ^ 1);
+                for (int n = 0; n < kCopies; ++n) copy_n(n, PAR ^ 1, PAR ^ 1);
+            }
+            if (stamp) stamps[1] = (int)__builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) {
 #pragma unroll
@@ -296,6 +309,10 @@ wino3x3_f32_kernel(const ConvArgs a) {
                 for (int c = 0; c < 4; ++c) rows_d(d, c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cols_d(d, vnext[0], i);
+                if (stamp) {
+                    // make the transform's end observable: the stamp depends on its result
+                    stamps[2] = (int)__builtin_amdgcn_s_memtime() + (vnext[0][15][1] == 12345.f);
+                }
 #pragma unroll
                 for (int x = 0; x < 16; ++x) {
                     f32x4 wq[CB / 2];
@@ -310,6 +327,16 @@ wino3x3_f32_kernel(const ConvArgs a) {
                                                     acc[tb][cb][x]);
                 }
             }
+            if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0);
+            if (stamp) stamps[4] = (int)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (stamp) stamps[5] = (int)__builtin_amdgcn_s_memtime();
+            ++k_stamp;
+            if (comp_ch == 0) q0 = s_ctrl[0];
+            advance(pit, pch, true);
+            advance(wit, wch, false);
+            return;
         } else {
         // weight fragments are read one slice ahead of the MFMAs that use them (the slices are
         // pinned by scheduling barriers, so nothing else prefetches them)
