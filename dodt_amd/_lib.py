@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdodt_hip.so')
+# DODT_HIP_LIB: another build of the same library (A/B timing by tools/)
+LIB_PATH = os.environ.get('DODT_HIP_LIB') or os.path.join(_HERE, 'lib', 'libdodt_hip.so')
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED = 0, 1, 2, 3
 PTS_VELO_XYZI, PTS_CAM_3XN = 0, 1

@@ -156,7 +156,7 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         advance();
     }
     // chunk 0 has landed once all but the newest (S - 2) chunks' copies are done
-    __builtin_amdgcn_s_waitcnt(0xc07f & ~0xc00f | (((S - 2) * Cfg::kCopies) & 0xf) |
+    __builtin_amdgcn_s_waitcnt((0xc07f & ~0xc00f) | (((S - 2) * Cfg::kCopies) & 0xf) |
                                ((((S - 2) * Cfg::kCopies) >> 4) << 14));
     __builtin_amdgcn_s_barrier();
 
@@ -197,7 +197,7 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
             }
             // the next chunk has landed once all but the newest (S - 2) chunks' copies are done
             // (vmcnt is in issue order; an epilogue's stores are older than those copies)
-            __builtin_amdgcn_s_waitcnt(0xc07f & ~0xc00f | (((S - 2) * Cfg::kCopies) & 0xf) |
+            __builtin_amdgcn_s_waitcnt((0xc07f & ~0xc00f) | (((S - 2) * Cfg::kCopies) & 0xf) |
                                        ((((S - 2) * Cfg::kCopies) >> 4) << 14));
             __builtin_amdgcn_s_barrier();
             if (comp_ch == 0) k2 = s_ctrl[0];     // the item claimed in this step: third in line

@@ -348,6 +348,8 @@ class FramePairPipeline(object):
         FC = self.feat_c
         bev_hw, img_hw = (self.bev_fh, self.bev_fw), (self.img_fh, self.img_fw)
         plane = cfg['ground_plane']
+        if os.environ.get('DODT_PIPE_NO_TAIL'):      # (tools/: the step without its tail)
+            return
         for f in range(nf):
             c, b, A = self.sides[f % ns], fr[f], counts[f]
             computed = heads is None

@@ -13,6 +13,8 @@ static const Kind kinds[] = {
     {"f32 32x32x2   (4 acc sets)", 4 * 4096.0},  {"f32 16x16x1 4B (4 acc sets)", 4 * 2048.0},
     {"f32 32x32x1 2B (2 acc sets)", 2 * 4096.0}, {"f32 4x4x1 16B (8 acc sets)", 8 * 512.0},
     {"bf16 32x32x16 (4 acc sets)", 4 * 32768.0},
+    {"f32 16x16x4   (1 acc set: back to back dependent)", 8 * 2048.0}, {"f32 16x16x4   (2 acc sets)", 8 * 2048.0},
+    {"f32 16x16x4   (4 acc sets)", 8 * 2048.0}, {"f32 32x32x2   (1 acc set)", 4 * 4096.0}, {"f32 32x32x2   (2 acc sets)", 4 * 4096.0},
 };
 
 template <int kind>
@@ -42,6 +44,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, long long* ticks
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, acc[j], 0, 0, 0);
         for (int j = 0; j < 2; ++j) s += acc[j][0];
+    } else if constexpr (kind >= 7 && kind <= 9) {
+        constexpr int N = kind == 7 ? 1 : kind == 8 ? 2 : 4;
+        f32x4 acc[N] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j % N] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j % N], 0, 0, 0);
+        for (int j = 0; j < N; ++j) s += acc[j][0];
+    } else if constexpr (kind == 10 || kind == 11) {
+        constexpr int N = kind == 10 ? 1 : 2;
+        f32x16 acc[N] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j % N] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j % N], 0, 0, 0);
+        for (int j = 0; j < N; ++j) s += acc[j][0];
     } else {
         f32x16 acc[4] = {};
         bf16x8 av, bv;
@@ -70,13 +88,13 @@ void run(float* d, long long* t) {
         }
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long h[2]; hipMemcpy(h, t, 16, hipMemcpyDeviceToHost);
-        printf("%-28s %d waves/SIMD: %7.3f ms %7.1f TFLOP/s   first block: %.0f MHz shader clock\n", kinds[kind].name,
+        printf("%-50s %d waves/SIMD: %7.3f ms %7.1f TFLOP/s   first block: %.0f MHz shader clock\n", kinds[kind].name,
                blocks / 256, ms, kinds[kind].flop * iters * 4.0 * blocks / ms / 1e9, 100.0 * h[0] / h[1]);
     }
 }
 
 int main() {
     float* d; long long* t; hipMalloc(&d, 4096 * 256 * 4); hipMalloc(&t, 16);
-    run<0>(d, t); run<1>(d, t); run<2>(d, t); run<3>(d, t); run<4>(d, t); run<5>(d, t); run<6>(d, t);
+    run<0>(d, t); run<1>(d, t); run<2>(d, t); run<3>(d, t); run<4>(d, t); run<5>(d, t); run<6>(d, t); run<7>(d, t); run<8>(d, t); run<9>(d, t); run<10>(d, t); run<11>(d, t);
     return 0;
 }
