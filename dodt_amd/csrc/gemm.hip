@@ -23,9 +23,11 @@
 #include <cstdlib>
 #include <mutex>
 #include <set>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -293,6 +295,175 @@ int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
     return DODT_OK;
 }
 
+// ---- the large layers (stage-2 / correlation FC 2048-wide): LDS-DMA staged form ------------------
+// Same arithmetic and weight blocking as fc_mfma_kernel; what changed is how a stage reaches LDS and
+// how many waves share a SIMD:
+//   * x rows and weight blocks go global -> LDS by buffer_load_dwordx4 ... lds (no staging
+//     registers, no ds_write pass, no vector instructions: on this chip a wave's vector work does
+//     not overlap the fp32 MFMAs of its SIMD, tools/micro/coissue.hip), three stages of 32 k in a
+//     ring, the copies of stage s + 2 issued while stage s computes; rows beyond M and the tail of
+//     the weight block read zeros through the descriptor's bound.
+//   * the x image is stored unpadded, the 16-byte k-quads of row r XOR-swizzled by (r >> 1) & 7 (the
+//     permutation is applied to the source address of each slot): the 16 rows one LDS pass serves
+//     fall into 16 different bank groups.
+//   * 64 x 64 tiles (one 32x32 MFMA tile per wave): M = 1024, N = 2048 gives 512 workgroups of
+//     48 KB (72 KB with the fused mean: the second crop has its own image, the average is taken
+//     on the fragment) -- two per CU, two waves per SIMD, one covering the other's waits.
+//   * the workgroup -> tile map gives every XCD a contiguous range of tiles with the n-tile
+//     running fastest: its workgroups share x rows and sweep K together, so most fills hit its L2
+//     (fill rate from L2 ~50 B/clk/CU against ~10.5 from beyond it, tools/micro/fill_rate.hip).
+// Needs K % 32 == 0, ldx % 4 == 0 (16-byte aligned rows) and the 128-wide weight blocking.
+constexpr int kDmaBM = 64, kDmaBN = 64, kDmaBK = 32, kDmaStages = 3;
+constexpr int kDmaXFloats = kDmaBM * kDmaBK, kDmaWFloats = kDmaBK * kDmaBN;
+
+template <bool FUSE>
+__global__ void __launch_bounds__(256, 2)
+fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    using dodt::blds16;
+    using dodt::i32x4_t;
+    using dodt::kOob;
+    using dodt::make_rsrc;
+    constexpr int kStage = kDmaXFloats * (FUSE ? 2 : 1) + kDmaWFloats;   // floats
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // XCD-aware tile order: workgroup id -> XCD id % 8 (round-robin dispatch); XCD j takes the j-th
+    // eighth of the tile list (n fastest)
+    const int T = tiles_m * tiles_n;
+    int tile = blockIdx.x;
+    if (T % 8 == 0) tile = (int)(blockIdx.x % 8) * (T / 8) + (int)(blockIdx.x / 8);
+    const int mt = tile / tiles_n, nt0 = tile % tiles_n;
+    const int m0 = mt * kDmaBM;
+    const int M = a.d_m ? min(*a.d_m, a.M) : a.M;
+    if (m0 >= M) return;
+    const int nstages = a.K / kDmaBK;
+
+    // ---- copy plan: per stage 8 x pieces (8 rows of 128 B each) [+ 8 of the second input] and
+    //      8 weight pieces ((q, h) rows of 64 features); wave w issues pieces w, w + 4 ---------------
+    const int rows = min(M - m0, kDmaBM);
+    const i32x4_t x_rsrc = make_rsrc(a.x + (size_t)m0 * a.ldx, (unsigned)(((size_t)(rows - 1) * a.ldx + a.K) * 4));
+    i32x4_t x2_rsrc = x_rsrc;
+    if (FUSE) x2_rsrc = make_rsrc(a.x2 + (size_t)m0 * a.ldx, (unsigned)(((size_t)(rows - 1) * a.ldx + a.K) * 4));
+    // weights: block of 128 features [K/8][h][128][4]; this tile's 64 are columns n0 % 128 ..
+    const int n0 = nt0 * kDmaBN;
+    const float* wblk = a.w + ((size_t)(n0 / 128) * (a.Kp / 8) * 2 * 128 + (n0 % 128)) * 4;
+    const i32x4_t w_rsrc = make_rsrc(wblk, (unsigned)(((size_t)(a.Kp / 8) * 2 * 128 - (n0 % 128)) * 16));
+    int x_off[2], w_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int piece = wave + 4 * k;                  // 0 .. 7
+        const int row = piece * 8 + (lane >> 3), cq = (lane & 7) ^ ((row >> 1) & 7);
+        x_off[k] = row < rows ? (row * a.ldx + cq * 4) * 4 : kOob;
+        w_off[k] = (piece * 128 + lane) * 16;            // (q, h) = piece: row of 128 features
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    auto issue = [&](int st, int buf) {       // scalar arithmetic only (see blds16s)
+        const unsigned sX = lds0 + (unsigned)(buf * kStage) * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned piece = (unsigned)(wave + 4 * k) * 1024;
+            dodt::blds16s(x_rsrc, x_off[k], st * (kDmaBK * 4), sX + piece);
+            if (FUSE) dodt::blds16s(x2_rsrc, x_off[k], st * (kDmaBK * 4), sX + kDmaXFloats * 4 + piece);
+            dodt::blds16s(w_rsrc, w_off[k], st * (8 * 128 * 16), sX + kDmaXFloats * (FUSE ? 8 : 4) + piece);
+        }
+    };
+    constexpr int kPerStage = FUSE ? 6 : 4;              // copies per wave and stage
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // fragment addresses inside a stage: x row (wm * 32 + li), k-quad 2 q + lh, swizzled;
+    // weights row (2 q + lh), feature wn * 32 + li
+    const int xrow = wm * 32 + li;
+    const int xsw = (xrow >> 1) & 7;
+    const int x_base = xrow * kDmaBK;
+    const int w_base = kDmaXFloats * (FUSE ? 2 : 1) + (lh * kDmaBN + wn * 32 + li) * 4;
+
+    // per-lane fragment offsets inside a stage (floats): with the buffer number a compile-time
+    // constant (ring walked by an unrolled-by-three loop) every LDS read is base + immediate
+    int xo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xo[q] = x_base + (((2 * q + lh) ^ xsw) * 4);
+    auto stage = [&](auto bufc, int st) {
+        constexpr int BUF = decltype(bufc)::value;
+        // stage st has landed once all but the copies of stage st + 1 are done
+        if (st + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0f70 | kPerStage);   // vmcnt(kPerStage)
+        else __builtin_amdgcn_s_waitcnt(0x0f70);                                  // vmcnt(0)
+        __builtin_amdgcn_s_barrier();     // ... for every wave; buffer (BUF + 2) % 3 is free
+        if (st + 2 < nstages) issue(st + 2, (BUF + 2) % kDmaStages);
+        const float* sS = smem + BUF * kStage;
+        f32x4 xf[4], wf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xf[q] = *reinterpret_cast<const f32x4*>(sS + xo[q]);
+            wf[q] = *reinterpret_cast<const f32x4*>(sS + w_base + q * (2 * kDmaBN * 4));
+        }
+        f32x4 x2[FUSE ? 4 : 1];
+        if (FUSE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x2[q] = *reinterpret_cast<const f32x4*>(sS + kDmaXFloats + xo[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // all fragment reads ahead of the MFMAs
+        if (FUSE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xf[q][e] = (xf[q][e] + x2[q][e]) / 2.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[q][s2], wf[q][s2], acc, 0, 0, 0);
+    };
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    for (int st = 0; st < nstages; st += 3) {
+        stage(std::integral_constant<int, 0>{}, st);
+        if (st + 1 < nstages) stage(std::integral_constant<int, 1>{}, st + 1);
+        if (st + 2 < nstages) stage(std::integral_constant<int, 2>{}, st + 2);
+    }
+    // epilogue: bias + activation; lane = feature, registers = samples
+    const int n = n0 + wn * 32 + li;
+    const float b = a.bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && n < a.N) {
+            float v = acc[r] + b;
+            if (a.relu) v = fmaxf(v, 0.0f);
+            a.y[(size_t)m * a.ldy + n] = v;
+        }
+    }
+}
+
+int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
+    const int tiles_m = dodt::ceil_div(a.M, kDmaBM), tiles_n = Npad / kDmaBN;
+    auto go = [&](auto kernel, size_t lds) -> hipError_t {
+        static std::mutex mu;
+        static std::set<const void*> prepared;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!prepared.count(reinterpret_cast<const void*>(kernel))) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                prepared.insert(reinterpret_cast<const void*>(kernel));
+            }
+        }
+        hipLaunchKernelGGL(kernel, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (a.x2) e = go(&fc_dma_kernel<true>, (size_t)kDmaStages * (2 * kDmaXFloats + kDmaWFloats) * 4);
+    else e = go(&fc_dma_kernel<false>, (size_t)kDmaStages * (kDmaXFloats + kDmaWFloats) * 4);
+    DODT_HIP_CHECK(e);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
 }  // namespace
 
 struct dodt_fc {
@@ -378,6 +549,11 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
         return launch_fc<128, 32, 4, 1, 32, 64, true>(s, a, f->Npad);
     }
     if (f->BN == 128) {
+        // the 2048-wide layers: LDS-DMA staged kernel (DODT_FC_DMA=0: the register-staged one)
+        static const bool dma = !(getenv("DODT_FC_DMA") && atoi(getenv("DODT_FC_DMA")) == 0);
+        if (dma && f->K % kDmaBK == 0 && ldx % 4 == 0 && f->K >= 2 * kDmaBK &&
+            ((size_t)d_x % 16 == 0) && (!d_x2 || (size_t)d_x2 % 16 == 0))
+            return launch_fc_dma(s, a, f->Npad);
         // tile shapes measured at the heads' sizes (M = 1024, N = K = 2048): 64x128 with a
         // 64-deep stage 97 TFLOP/s; 64x64 tiles and 32-deep stages within 3 % of it; 128x128
         // (2x2 MFMA tiles per wave) 106 at M = 4096 but only 128 workgroups at M = 1024
