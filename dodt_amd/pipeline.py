@@ -15,13 +15,15 @@ one batch.  Streams: the two conv stacks each have their own (they run side by
 side); every frame has a side stream for its "prep" (points -> BEV maps, anchors, image
 preprocessing) and its "tail" (crops, heads, decode, NMS), so the single-workgroup
 stages (NMS scan) of different frames overlap (four streams in all at one pair per
-step: the hardware-queue budget of a process).  Steps are
-software-pipelined: while the conv stacks of step k run, the prep streams already
-build the inputs of step k+1 and the tail streams finish step k-1; inputs,
-feature maps, per-frame buffers and detection records are double-buffered by step
-parity for that, and `finish()` drains the last step.  Everything stays on the
-device; the only host round trip per step is the kept-anchor count of each frame,
-fetched one step after it was produced (the host never waits for the GPU).
+step: the hardware-queue budget of a process).  A frame's prep and tail share its side
+stream, so the order on that stream is prep k, tail k-1, prep k+1, ...: the prep of step
+k+1 is enqueued by run(k+1) behind the tail of step k-1 and in front of the convs of its own
+step (0.1 ms; it does NOT run under the convs of step k); what overlaps is the tail of step
+k with the convs of step k+1.  Inputs, feature maps, per-frame buffers and detection records
+are double-buffered by step parity for that, and `finish()` drains the last step.
+Everything stays on the device; the only host round trip per step is the kept-anchor count
+of each frame, fetched one step after it was produced (the host runs one step ahead of the
+GPU and otherwise waits in that read).
 """
 import os
 

@@ -204,3 +204,65 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
     with pytest.raises(ValueError):
         pipe.run([], [], [], heads=[{}])
     pipe.close()
+
+
+def test_pair_free_running_detection_agreement(ctx):
+    """Free-running check: the whole pair on the device -- extractors, heads, both
+    NMS, records -- against the oracle run end to end on the same raw inputs, nothing fed back.
+    Not an index-exact statement (a logit that differs in its last bits may reorder near-tied NMS
+    candidates; the stage-wise test above is the parity statement): detections are matched greedily
+    by box distance and the agreement is reported, so that drift across stages would be visible.
+    Bars: >= 95 % of the oracle's proposals have a device proposal within 1e-3 (anchor
+    coordinates), >= 90 % of its final detections have a device detection whose 7 box parameters
+    and score agree to 1e-3, the detection counts differ by at most 10 %."""
+    hp = synth.head_params()
+    w = synth.pipeline_weights(C)
+    pipe = FramePairPipeline(ctx, C, **w, rpn_nms_size=1024, head_params=hp)
+    frames = (0, 2)
+    pts = [synth.lidar_frame(4, f) for f in frames]
+    imgs = [synth.image_frame(4, f) for f in frames]
+    pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts], [ctx.array(i) for i in imgs])
+    pipe.finish()
+    ctx.sync()
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    inps, feats = [], []
+    for k in range(2):
+        inp = opipe.frame_inputs(pts[k], C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2,
+                                 synth.IMAGE_WH)
+        inps.append(inp)
+        feats.append(opipe.extract(inp['bev'], imgs[k], w['bev_params'], w['img_params'],
+                                   C['img_dims']))
+    want = opipe.pair_detections_computed(inps, feats, hp, C, synth.P2, synth.IMAGE_WH, 1024)
+
+    def matched(got, ref, tol):
+        """Fraction of ref rows with an unused got row within tol (max abs difference)."""
+        used = np.zeros(len(got), bool)
+        hits = 0
+        for r in ref:
+            d = np.abs(got - r).max(axis=1)
+            d[used] = np.inf
+            j = int(np.argmin(d)) if len(d) else -1
+            if j >= 0 and d[j] <= tol:
+                used[j] = True
+                hits += 1
+        return hits / max(len(ref), 1)
+
+    for f in range(2):
+        b = pipe.fr[f]
+        n_top = int(b['top_count'].download()[0])
+        got_top = b['top_anchors'].download()[:n_top]
+        ref_top = want[f]['top_anchors']
+        frac_top = matched(got_top, ref_top, 1e-3)
+        n_det = int(b['det_count'].download()[0])
+        ref_n = int(want[f]['n_det']) if 'n_det' in want[f] else len(want[f]['det_idx'])
+        # records: box_3d (7) + score in the evaluator's layout
+        got_rec = recs[f][:n_det, :8]
+        ref_rec = want[f]['records'][:ref_n, :8]
+        frac_det = matched(got_rec, ref_rec, 1e-3)
+        print('frame %d: proposals %d / %d, agreement %.4f; detections %d / %d, agreement %.4f'
+              % (f, n_top, len(ref_top), frac_top, n_det, ref_n, frac_det))
+        assert abs(n_top - len(ref_top)) <= 0.02 * len(ref_top)
+        assert frac_top >= 0.95
+        assert abs(n_det - ref_n) <= max(2, 0.1 * ref_n)
+        assert frac_det >= 0.90
+    pipe.close()
