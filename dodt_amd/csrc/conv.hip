@@ -29,6 +29,7 @@ using dodt::KernelVariant;
 using dodt::Inst;
 using dodt::InstSmall;
 using dodt::InstWino;
+using dodt::InstWino43;
 using dodt::tail_only;
 using dodt::f32x4;
 
@@ -63,6 +64,7 @@ const std::vector<KernelVariant>& variants() {
         InstWino<1, 4>::variant(),
         InstWino<2, 2>::variant(),
         InstWino<1, 2>::variant(),    // 16 x 16 px x 32 ch, 128 accumulators: two workgroups per CU
+        InstWino43::variant(),        // F(4x4,3x3): 32 x 16 px x 32 ch, one workgroup per CU
     };
     static const std::vector<KernelVariant> all = [] {
         std::vector<KernelVariant> a = v;
@@ -75,7 +77,7 @@ const std::vector<KernelVariant>& variants() {
 
 // smallest padded pixel count wins; ties go to the larger output tile
 int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int parts, int batch,
-                 int num_cus) {
+                 int num_cus, bool last) {
     const auto& vs = variants();
     const bool small = Cin < dodt::kCK;
     int best = -1;
@@ -85,11 +87,18 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     // two workgroups per CU (both stacks 3.0 ms against 4.8 ms for the direct kernels);
     // 1 = the 256-accumulator variants, one workgroup per CU (no faster than direct: a lone
     // wave per SIMD issues in order and nothing hides behind its MFMA bursts); 0 = direct.
-    static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 2;
+    // DODT_CONV_WINO: 4 (default) = F(4x4,3x3) (wino43_kernel.h) where it applies -- not the stack's
+    // last layer (NHWC output, fused bottleneck), which takes the F(2x2) kernel --, 2 = F(2x2,3x3)
+    // everywhere, 1 = its 256-accumulator variants, 0 = direct.
+    static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 4;
     if (wino_mode > 0 && !deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].wino || Cout % vs[i].BN != 0) continue;
-            if ((wino_mode == 2) != (vs[i].blocks_per_cu == 2)) continue;
+            if (vs[i].wino_m == 4) {
+                if (wino_mode == 4 && !last) return (int)i;
+                continue;
+            }
+            if ((wino_mode == 1) == (vs[i].blocks_per_cu == 2)) continue;
             if (best < 0 || vs[i].BN > vs[best].BN) best = (int)i;
         }
         if (best >= 0) return best;
@@ -584,7 +593,8 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         Layer l;
         l.name = name; l.deconv = deconv; l.H = h; l.W = w; l.Cin = cin; l.Cout = cout;
         l.src = src; l.src_coff = src_coff; l.dst = dst; l.dst_coff = dst_coff;
-        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, ex->parts, batch, ctx->num_cus);
+        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, ex->parts, batch, ctx->num_cus,
+                                 std::string(name) == "pyramid_fusion1");
         l.real_cin = cin;
         ex->layers.push_back(l);
     };
@@ -698,6 +708,39 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     }
     const KernelVariant& v = variants()[ln->variant];
     const int nchunks = l.Cin / v.CK;
+    if (v.wino && v.wino_m == 4) {
+        // F(4x4,3x3) filter transform U = G g G^T (6x6 points; float64 on the host, rounded once),
+        // blocked [n-tile][chunk][xi / 2][g = c / 2][cb][t][xi & 1][c & 1]: a lane (t, g) of channel
+        // block cb reads 16 bytes = its channel pair for two points
+        static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6},
+                                       {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
+                                       {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+        std::vector<float> u((size_t)36 * l.Cin * l.Cout, 0.0f);
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co) {
+                double gk[3][3], tmp[6][3];
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        gk[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
+                for (int i = 0; i < 6; ++i)
+                    for (int kx = 0; kx < 3; ++kx)
+                        tmp[i][kx] = G[i][0] * gk[0][kx] + G[i][1] * gk[1][kx] + G[i][2] * gk[2][kx];
+                const int nt = co / v.BN, n = co % v.BN, ch = ci / 8, c = ci % 8;
+                const int cb = n / 16, t = n % 16;
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        const double val = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                        const int xi = i * 6 + j;
+                        u[(((((((size_t)nt * nchunks + ch) * 18 + xi / 2) * 4 + c / 2) * 2 + cb) * 16 + t) * 2 +
+                           (xi & 1)) * 2 + (c & 1)] = (float)val;
+                    }
+            }
+        if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, u.size() * sizeof(float)));
+        DODT_HIP_CHECK(hipMemcpyAsync(ln->d_w, u.data(), u.size() * sizeof(float),
+                                      hipMemcpyHostToDevice, s));
+        DODT_HIP_CHECK(hipStreamSynchronize(s));
+        continue;
+    }
     if (v.wino) {
         // Winograd filter transform U = G g G^T (float64 on the host, rounded once to fp32),
         // G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]; blocked like the direct kernel's
@@ -959,7 +1002,10 @@ double dodt_extractor_mfma_flops(const dodt_extractor* ex) {
     double f = 0.0;
     for (const Layer& l : ex->layers) {
         const double direct = 2.0 * l.H * l.W * (double)l.Cout * 9.0 * l.real_cin * ex->batch;
-        f += variants()[l.main.variant].wino ? direct * 16.0 / 36.0 : direct;
+        {
+            const KernelVariant& kv = variants()[l.main.variant];
+            f += kv.wino ? direct * (kv.wino_m == 4 ? 36.0 / 144.0 : 16.0 / 36.0) : direct;
+        }
     }
     return f;
 }

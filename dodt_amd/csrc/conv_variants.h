@@ -5,6 +5,7 @@
 
 #include "conv_kernels.h"
 #include "wino_kernels.h"
+#include "wino43_kernel.h"
 #include "conv_bf16_dma.h"
 
 namespace dodt {
@@ -21,6 +22,7 @@ struct KernelVariant {
     int parts = 1;           // 2: split mode, every map is a hi + lo pair of bf16 maps
     bool wino = false;       // Winograd F(2x2,3x3) kernel (wino_kernels.h): 16 weight points, not 9 taps
     bool dma = false;        // bf16 kernel with LDS-DMA staging (conv_bf16_dma.h)
+    int wino_m = 2;          // Winograd output block: F(2x2,3x3) or F(4x4,3x3) (wino43_kernel.h)
 };
 
 inline KernelVariant tail_only(KernelVariant v) {
@@ -69,6 +71,25 @@ struct InstWino {
         KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, kCK, false, false, Cfg::TH, Cfg::kLdsBytes,
                         Cfg::kPipe ? 1 : 2, &launch, &prepare};
         v.wino = true;
+        return v;
+    }
+};
+
+struct InstWino43 {
+    using Cfg = Wino43Cfg;
+    static_assert(Cfg::kLdsBytes <= 160 * 1024, "variant does not fit the LDS");
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL(wino43_f32_kernel<0>, grid, dim3(256), Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wino43_f32_kernel<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, kCK, false, false, Cfg::TH, Cfg::kLdsBytes, 1,
+                        &launch, &prepare};
+        v.wino = true;
+        v.wino_m = 4;
         return v;
     }
 };
