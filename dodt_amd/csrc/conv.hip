@@ -95,7 +95,7 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].wino || Cout % vs[i].BN != 0) continue;
             if (vs[i].wino_m == 4) {
-                if (wino_mode == 4 && !last) return (int)i;
+                if (wino_mode == 4) return (int)i;
                 continue;
             }
             if ((wino_mode == 1) == (vs[i].blocks_per_cu == 2)) continue;

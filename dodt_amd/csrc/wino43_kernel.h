@@ -51,7 +51,7 @@ struct Wino43Cfg {
     static constexpr int kWFloats = 36 * 8 * BN;                      // 9216: 36 copies
     static constexpr int kWInstr = kWFloats / 256;
     static constexpr int kBufFloats = kPatchFloats + kWFloats;
-    static constexpr int kLdsBytes = 2 * kBufFloats * 4 + 16 + 1024;  // + control word + dummy slot
+    static constexpr int kLdsBytes = 2 * kBufFloats * 4 + 16 + 2048;  // + control word + bottleneck exchange
     static constexpr int kPatchPerWave = (kPatchInstr + 3) / 4;       // 5
     static constexpr int kWPerWave = kWInstr / 4;                     // 9
 };
@@ -325,6 +325,7 @@ wino43_f32_kernel(const ConvArgs a) {
                          : "+a"(acc[x]), "+a"(acc[x + 1]), "+a"(acc[x + 2]), "+a"(acc[x + 3]), "+a"(acc[x + 4]),
                            "+a"(acc[x + 5]), "+a"(acc[x + 6]), "+a"(acc[x + 7]), "+a"(acc[x + 8]),
                            "+a"(acc[x + 9]), "+a"(acc[x + 10]), "+a"(acc[x + 11]));
+        float bdot[4][4];      // bottleneck: this wave's partial dot per pixel of the lane's tile
         // ---- epilogue: Y = A^T M A (rows, then columns), batch-norm + ReLU, stores ----------------
         {
             const Item it = decode(comp_item);
@@ -342,6 +343,12 @@ wino43_f32_kernel(const ConvArgs a) {
                 wino43_at(acc[0 * 6 + j], acc[1 * 6 + j], acc[2 * 6 + j], acc[3 * 6 + j], acc[4 * 6 + j],
                           acc[5 * 6 + j], z[0][j], z[1][j], z[2][j], z[3][j]);
             float* obase = out + (size_t)((a.out_coff + c0) >> 3) * plane + ((a.out_coff + c0) & 7);
+            // fused 1x1 bottleneck of a stack's last layer (Cout == 32): per pixel a dot over the lane's
+            // four channels, + the lanes l ^ 16, l ^ 32 (the wave's other twelve), + the other channel
+            // block's wave through LDS
+            f32x4 bw = {0.f, 0.f, 0.f, 0.f};
+            if (a.bneck_w) bw = *reinterpret_cast<const f32x4*>(a.bneck_w + c0);
+            float* const sDot = smem + 2 * Cfg::kBufFloats + 4 + tb * 256;     // [tile t][4 x 4 pixels]
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 y[4];
@@ -355,8 +362,21 @@ wino43_f32_kernel(const ConvArgs a) {
                         y[j][k] = a.relu ? fmaxf(tv, 0.0f) : tv;
                     }
                     const int ox = ox0 + j;
-                    if (oy < a.H && ox < a.W && oy >= a.out_y0)
-                        *reinterpret_cast<f32x4*>(obase + ((size_t)(oy - a.out_y0) * a.W + ox) * 8) = y[j];
+                    const bool ok = oy < a.H && ox < a.W && oy >= a.out_y0;
+                    if (ok) {
+                        if (a.out_nhwc)
+                            *reinterpret_cast<f32x4*>(out + ((size_t)(oy - a.out_y0) * a.W + ox) * a.out_ld +
+                                                      a.out_coff + c0) = y[j];
+                        else
+                            *reinterpret_cast<f32x4*>(obase + ((size_t)(oy - a.out_y0) * a.W + ox) * 8) = y[j];
+                    }
+                    if (a.bneck_w) {
+                        float d = ((y[j][0] * bw[0] + y[j][1] * bw[1]) + y[j][2] * bw[2]) + y[j][3] * bw[3];
+                        d += __shfl_xor(d, 16, 64);
+                        d += __shfl_xor(d, 32, 64);
+                        if (cbw == 1 && g == 0) sDot[t * 16 + i * 4 + j] = d;
+                        bdot[i][j] = d;
+                    }
                 }
                 // rows i = 0, 1 and 2, 3 hold the windows of a following VALID 2x2 max pool
                 if (a.pool_out) {
@@ -381,6 +401,24 @@ wino43_f32_kernel(const ConvArgs a) {
                     }
                 }
             }
+        }
+        if (a.bneck_w) {
+            __syncthreads();
+            if (cbw == 0 && g == 0) {
+                const Item it = decode(comp_item);
+                const float* sDot = smem + 2 * Cfg::kBufFloats + 4 + tb * 256;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int oy = it.ty0 + 4 * tyl + i, ox = it.tx0 + 16 * tb + 4 * txl + j;
+                        if (oy < a.H && ox < a.W && oy >= a.out_y0)
+                            a.bneck_out[(size_t)it.frame * a.bneck_frame_stride +
+                                        (size_t)(oy - a.out_y0) * a.W + ox] =
+                                fmaxf((bdot[i][j] + sDot[t * 16 + i * 4 + j]) * a.bneck_scale + a.bneck_shift, 0.0f);
+                    }
+            }
+            __syncthreads();      // the exchange area is free for the next item
         }
         comp_item = q0;
     }
