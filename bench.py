@@ -401,7 +401,7 @@ def main():
         traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
         traffic_src = t['source']
     common = dict(traffic=traffic, traffic_unit='bytes/launch', traffic_source=traffic_src,
-                  kernel='wino3x3_f32_kernel (24 launches per step) + conv3x3_mfma_kernel (6 transposed convs) '
+                  kernel='wino43_f32_kernel (24 launches per step) + conv3x3_mfma_kernel (6 transposed convs) '
                          '+ 2 first-layer launches',
                   launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
                   algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
@@ -413,16 +413,18 @@ def main():
     if args.conv_dtype == 'f32':
         # fp32 MFMA: 157.3 TFLOP/s dense (MI355X_MICROARCH.md chip table); every layer is
         # MFMA-bound at fp32.  `achieved` prices the ALGORITHMIC FLOPs (2 M N K of the direct
-        # form); the 3x3 stride-1 layers run as Winograd F(2x2,3x3), which executes
-        # 16/36 of them: what the matrix pipe really does is given beside it.
+        # form); the 3x3 stride-1 layers run as Winograd F(4x4,3x3), which executes
+        # 36/144 of them (so `frac` can exceed 1: the direct form's roof is not this algorithm's):
+        # what the matrix pipe really does is given beside it.
         executed = m['mfma_flops'] / (conv_ms * 1e-3) / 1e12
         roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=157.3, unit='TFLOP/s',
                         frac=round(achieved / 157.3, 4),
                         executed_gflop=round(m['mfma_flops'] / 1e9, 2),
                         executed_tflops=round(executed, 2),
                         executed_frac=round(executed / 157.3, 4),
-                        algorithm='Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 for the 3x3 '
-                                  'stride-1 layers (fp32 throughout), direct implicit GEMM for '
+                        algorithm='Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 for the 3x3 '
+                                  'stride-1 layers (fp32 throughout; 4x fewer multiplications than '
+                                  'the direct form priced by `achieved`), direct implicit GEMM for '
                                   'the first layer and the transposed convs', **common)
     elif args.conv_dtype == 'f32s':
         # split mode: three bf16 MFMAs per product term -> 3x the algorithmic FLOPs on the

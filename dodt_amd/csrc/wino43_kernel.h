@@ -242,22 +242,30 @@ wino43_f32_kernel(const ConvArgs a) {
             const unsigned pimg = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(
                 sPB + PAR * Cfg::kPatchFloats);
             const unsigned b0 = pimg + base_c[0], b1 = pimg + base_c[1];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
+            // column c + 1 is read while column c is transformed (lgkmcnt is a 4-bit counter: no
+            // more than two columns in flight); patch(k+1) copies go between the column passes
+            auto read_col = [&](int c) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
                     asm volatile("ds_read_b64 %0, %1 offset:%2"
                                  : "=v"(v[r][c])
                                  : "v"(c < 4 ? b0 : b1), "n"(tap_off_c(r, c)));
-            }
-            // the reads are asynchronous: wait, with the destinations as operands so that no use moves up
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(v[r][0]), "+v"(v[r][1]), "+v"(v[r][2]), "+v"(v[r][3]), "+v"(v[r][4]),
-                               "+v"(v[r][5]));
+            };
+            read_col(0);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
+                if (c + 1 < 6) {
+                    read_col(c + 1);
+                    // the reads are asynchronous: wait for column c (its destinations are operands so
+                    // that no use moves above the wait)
+                    asm volatile("s_waitcnt lgkmcnt(6)"
+                                 : "+v"(v[0][c]), "+v"(v[1][c]), "+v"(v[2][c]), "+v"(v[3][c]), "+v"(v[4][c]),
+                                   "+v"(v[5][c]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(v[0][c]), "+v"(v[1][c]), "+v"(v[2][c]), "+v"(v[3][c]), "+v"(v[4][c]),
+                                   "+v"(v[5][c]));
+                }
                 wino43_bt(v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c]);
                 if (c < Cfg::kPatchPerWave) copy_n(c, PAR ^ 1);
             }

@@ -13,7 +13,7 @@ for path in sys.argv[1:]:
         n = r['Kernel_Name']
         if 'conv3x3' not in n and 'fc_mfma' not in n and 'upsample' not in n and 'wino' not in n:
             continue
-        m = re.search(r'(conv3x3_\w+|wino3x3_\w+|fc_mfma_kernel|upsample\w+)<(.*?)>', n)
+        m = re.search(r'(conv3x3_\w+|wino3x3_\w+|wino43_\w+|fc_mfma_kernel|fc_dma_kernel|upsample\w+)<(.*?)>', n)
         key = (m.group(1)[8:14] + '<' + m.group(2) + '>') if m else n[:40]
         key += ' g%d' % (int(r['Grid_Size']) // 256)
         acc[key][r['Counter_Name']] += float(r['Counter_Value'])

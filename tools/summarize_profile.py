@@ -11,7 +11,7 @@ import sys
 
 
 def is_conv(name):
-    return 'conv3x3' in name or 'wino3x3' in name
+    return 'conv3x3' in name or 'wino3x3' in name or 'wino43' in name
 
 
 tag = sys.argv[1]
@@ -40,7 +40,7 @@ for r in rows:
     if is_conv(r['Name']):
         conv_ns += float(r['TotalDurationNs'])
         conv_calls += int(r['Calls'])
-lines += ['', 'conv kernels (wino3x3_* + conv3x3_*): %d launches, %.2f ms total, average launch %.1f us '
+lines += ['', 'conv kernels (wino43_* + wino3x3_* + conv3x3_*): %d launches, %.2f ms total, average launch %.1f us '
           '(the two nets overlap on two streams during the timed steps, which stretches '
           'each kernel)' % (conv_calls, conv_ns / 1e6, conv_ns / 1e3 / max(conv_calls, 1))]
 # the roofline section of bench.py: the LAST reps forwards of each net, run alone
@@ -109,7 +109,7 @@ if traffic:
             k, tot / 1e6, n, tot / 1e6 / max(n, 1)))
 if len(traffic) == 2:
     per = {k: tot / max(n, 1) for k, (tot, n) in traffic.items()}
-    json.dump({'kernel': 'wino3x3_* + conv3x3_* (all conv launches of the timed steps)',
+    json.dump({'kernel': 'wino43_* + wino3x3_* + conv3x3_* (all conv launches of the timed steps)',
                'fetch_bytes_per_launch': per['fetch'], 'write_bytes_per_launch': per['write'],
                'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 '
                          '(gfx950 correction), profiles/%s_summary.md' % tag},
