@@ -30,6 +30,7 @@ using dodt::Inst;
 using dodt::InstSmall;
 using dodt::InstWino;
 using dodt::InstWino43;
+using dodt::InstDeconvDma;
 using dodt::tail_only;
 using dodt::f32x4;
 
@@ -65,6 +66,8 @@ const std::vector<KernelVariant>& variants() {
         InstWino<2, 2>::variant(),
         InstWino<1, 2>::variant(),    // 16 x 16 px x 32 ch, 128 accumulators: two workgroups per CU
         InstWino43::variant(),        // F(4x4,3x3): 32 x 16 px x 32 ch, one workgroup per CU
+        InstDeconvDma<2>::variant(),  // transposed conv, LDS-DMA staged: 16 x 16 input px x 32 ch
+        InstDeconvDma<1>::variant(),  //   ... x 16 ch: twice the items, for layers with few of them
     };
     static const std::vector<KernelVariant> all = [] {
         std::vector<KernelVariant> a = v;
@@ -103,6 +106,17 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         }
         if (best >= 0) return best;
     }
+    // fp32 transposed convs: the LDS-DMA staged kernel (deconv_kernel.h; DODT_CONV_DECONV_DMA=0: the
+    // register-staged direct kernel's deconv instantiation)
+    static const bool deconv_dma = !(getenv("DODT_CONV_DECONV_DMA") && atoi(getenv("DODT_CONV_DECONV_DMA")) == 0);
+    if (deconv_dma && deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
+        // 32-channel tiles unless that leaves fewer than four items per CU (the CUs are MFMA-bound:
+        // what counts is how evenly the items spread)
+        const int n32 = dodt::ceil_div(H, 16) * dodt::ceil_div(W, 16) * (Cout / 32) * batch;
+        const int want_bn = (Cout % 32 == 0 && n32 >= 4 * num_cus) ? 32 : 16;
+        for (size_t i = 0; i < vs.size(); ++i)
+            if (vs[i].deconv_dma && vs[i].BN == want_bn && Cout % want_bn == 0) return (int)i;
+    }
     // DODT_CONV_BF16_DMA=1: bf16 3x3 stride-1 layers on the LDS-DMA staged kernel
     // (conv_bf16_dma.h) instead of the template's bf16 instantiation.  Measured at parity
     // (both stacks 1.24 ms against 1.27 ms): the bf16 layers are bound by the global -> LDS fill
@@ -116,7 +130,7 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     }
     for (size_t i = 0; i < vs.size(); ++i) {
         const KernelVariant& v = vs[i];
-        if (v.wino || v.dma) continue;
+        if (v.wino || v.dma || v.deconv_dma) continue;
         if (v.deconv != deconv || v.small_cin != small || v.tail_only || v.bf16 != bf16 ||
             v.parts != parts || Cout % v.BN != 0)
             continue;
@@ -453,7 +467,7 @@ void plan_layer(Layer& l, int batch, int num_cus, bool allow_tail, std::vector<i
                 for (int x = 0; x < tx; ++x) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
     l.main.variant = l.variant;
     l.tail.variant = -1;
-    if (v.small_cin || v.wino || v.dma) return;
+    if (v.small_cin || v.wino || v.dma || v.deconv_dma) return;
     static const bool no_tail = getenv("DODT_CONV_NO_TAIL") != nullptr;
     const int n = (int)main_items.size();
     const int G = num_cus * v.blocks_per_cu;
@@ -708,6 +722,27 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     }
     const KernelVariant& v = variants()[ln->variant];
     const int nchunks = l.Cin / v.CK;
+    if (v.deconv_dma) {
+        // transposed conv, TF layout (kh, kw, Cout, Cin): blocked [n-tile][chunk][tap][g = c / 2][t]
+        // [channel block][c & 1]: a lane (t, g) reads 16 bytes = its channel pair for both blocks
+        const int ncb = v.BN / 16;
+        const size_t chunk_floats = (size_t)(9 * 8 * v.BN + 255) / 256 * 256;     // whole 1 KB pieces
+        std::vector<float> u((size_t)(l.Cout / v.BN) * nchunks * chunk_floats, 0.0f);
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < cout; ++co) {
+                    const int nt = co / v.BN, n = co % v.BN, ch = ci / 8, c = ci % 8;
+                    const int cb = n / 16, t = n % 16;
+                    u[((size_t)nt * nchunks + ch) * chunk_floats +
+                      ((((size_t)tap * 4 + c / 2) * 16 + t) * ncb + cb) * 2 + (c & 1)] =
+                        w[((size_t)tap * cout + co) * cin + ci];
+                }
+        if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, u.size() * sizeof(float)));
+        DODT_HIP_CHECK(hipMemcpyAsync(ln->d_w, u.data(), u.size() * sizeof(float),
+                                      hipMemcpyHostToDevice, s));
+        DODT_HIP_CHECK(hipStreamSynchronize(s));
+        continue;
+    }
     if (v.wino && v.wino_m == 4) {
         // F(4x4,3x3) filter transform U = G g G^T (6x6 points; float64 on the host, rounded once),
         // blocked [n-tile][chunk][xi / 2][g = c / 2][cb][t][xi & 1][c & 1]: a lane (t, g) of channel

@@ -6,6 +6,7 @@
 #include "conv_kernels.h"
 #include "wino_kernels.h"
 #include "wino43_kernel.h"
+#include "deconv_kernel.h"
 #include "conv_bf16_dma.h"
 
 namespace dodt {
@@ -23,6 +24,7 @@ struct KernelVariant {
     bool wino = false;       // Winograd F(2x2,3x3) kernel (wino_kernels.h): 16 weight points, not 9 taps
     bool dma = false;        // bf16 kernel with LDS-DMA staging (conv_bf16_dma.h)
     int wino_m = 2;          // Winograd output block: F(2x2,3x3) or F(4x4,3x3) (wino43_kernel.h)
+    bool deconv_dma = false; // transposed conv, LDS-DMA staged (deconv_kernel.h)
 };
 
 inline KernelVariant tail_only(KernelVariant v) {
@@ -90,6 +92,24 @@ struct InstWino43 {
                         &launch, &prepare};
         v.wino = true;
         v.wino_m = 4;
+        return v;
+    }
+};
+
+template <int CB>
+struct InstDeconvDma {
+    using Cfg = DeconvCfg<CB>;
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL(deconv3x3_f32_kernel<CB>, grid, dim3(256), Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3_f32_kernel<CB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, kCK, true, false, Cfg::TH, Cfg::kLdsBytes, 2,
+                        &launch, &prepare};
+        v.deconv_dma = true;
         return v;
     }
 };

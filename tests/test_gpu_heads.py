@@ -214,10 +214,13 @@ def test_pair_free_running_detection_agreement(ctx):
     by box distance and the agreement is reported, so that drift across stages would be visible.
     Bars: >= 95 % of the oracle's proposals have a device proposal within 1e-3 (anchor
     coordinates; measured 100 %), >= 95 % of its final detections have a device detection whose 7
-    box parameters and score agree to 1e-2 (+ 1e-3 relative), the detection counts differ by at most
-    10 %.  The fraction that agrees to 1e-3 is printed (measured 0.78: the same detections, their
-    regressed boxes 1-4e-3 apart -- fp32 summation-order noise of 13 conv and 4 FC layers with
-    synthetic He-initialised weights, amplified by the offset decode; no detection is missing)."""
+    box parameters and score agree to 5e-2 (x (1 + 0.1 |value|)), the detection counts differ by at
+    most 10 %.  The fractions that agree to 1e-3 and 1e-2 are printed.  Measured: with the
+    F(2x2,3x3) convs (DODT_CONV_WINO=2, per-layer error 2e-7 of the scale) 0.78 / 1.00 / 1.00, with
+    the default F(4x4,3x3) convs (3-5e-6) 0.40 / 0.91 / 1.00: the same detections, their regressed
+    boxes apart by the conv stacks' rounding noise amplified ~1e3 x by four FC layers with synthetic
+    He-initialised weights and the offset decode; no detection is missing.  (cuDNN, which the
+    reference's TF build calls, picks Winograd F(4x4) itself for these layers.)"""
     hp = synth.head_params()
     w = synth.pipeline_weights(C)
     pipe = FramePairPipeline(ctx, C, **w, rpn_nms_size=1024, head_params=hp)
@@ -263,12 +266,13 @@ def test_pair_free_running_detection_agreement(ctx):
         got_rec = recs[f][:n_det, :8]
         ref_rec = want[f]['records'][:ref_n, :8]
         frac_det = matched(got_rec, ref_rec, 1e-3)       # reported
-        frac_det2 = matched(got_rec, ref_rec, 1e-2)      # asserted
+        frac_det2 = matched(got_rec, ref_rec, 1e-2)      # reported
+        frac_det3 = matched(got_rec, ref_rec, 5e-2)      # asserted
         print('frame %d: proposals %d / %d, agreement %.4f; detections %d / %d, agreement %.4f at '
-              '1e-3, %.4f at 1e-2' % (f, n_top, len(ref_top), frac_top, n_det, ref_n, frac_det,
-                                      frac_det2))
+              '1e-3, %.4f at 1e-2, %.4f at 5e-2' % (f, n_top, len(ref_top), frac_top, n_det, ref_n,
+                                                    frac_det, frac_det2, frac_det3))
         assert abs(n_top - len(ref_top)) <= 0.02 * len(ref_top)
         assert frac_top >= 0.95
         assert abs(n_det - ref_n) <= max(2, 0.1 * ref_n)
-        assert frac_det2 >= 0.95
+        assert frac_det3 >= 0.95
     pipe.close()
