@@ -594,8 +594,8 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
             return DODT_ERR_HIP;
         }
     }
-    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 512 * sizeof(int)));
-    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 512 * sizeof(int), ctx->stream));
+    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 2048 * sizeof(int)));
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 2048 * sizeof(int), ctx->stream));
     DODT_HIP_CHECK(hipMalloc(&ex->d_zeros, 256));
     DODT_HIP_CHECK(hipMemsetAsync(ex->d_zeros, 0, 256, ctx->stream));
     // the pad rows of X0 stay zero for the life of the extractor

@@ -51,7 +51,11 @@ struct Wino43Cfg {
     static constexpr int kWFloats = 36 * 8 * BN;                      // 9216: 36 copies
     static constexpr int kWInstr = kWFloats / 256;
     static constexpr int kBufFloats = kPatchFloats + kWFloats;
-    static constexpr int kLdsBytes = 2 * kBufFloats * 4 + 16 + 2048;  // + control word + bottleneck exchange
+    // exactly 112 KB: a 48 KB workgroup of the FC kernel (gemm.hip) fits beside it on a CU, so the
+    // tail's GEMMs can use the vector-pipe time this kernel's waves spend waiting.  The work queue's
+    // ticket travels through a per-workgroup mailbox in global memory and the bottleneck's
+    // exchange area aliases a patch image that is free during an epilogue.
+    static constexpr int kLdsBytes = 2 * kBufFloats * 4;
     static constexpr int kPatchPerWave = (kPatchInstr + 3) / 4;       // 5
     static constexpr int kWPerWave = kWInstr / 4;                     // 9
 };
@@ -107,7 +111,7 @@ wino43_f32_kernel(const ConvArgs a) {
     using Cfg = Wino43Cfg;
     constexpr int BN = Cfg::BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* s_ctrl = reinterpret_cast<int*>(smem + 2 * Cfg::kBufFloats);
+    int* const mailbox = a.counter_base + 1024 + blockIdx.x;      // successor ticket of this workgroup
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -229,7 +233,9 @@ wino43_f32_kernel(const ConvArgs a) {
         const bool stamp = (a.debug & 32) && blockIdx.x == 1 && tid == 0 && k_stamp < 12;
         int* stamps = a.counter_base + 32 + (k_stamp < 12 ? k_stamp : 0) * 6;
         if (stamp) stamps[0] = (int)__builtin_amdgcn_s_memtime();
-        if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+        if (comp_ch == 0 && tid == 0)
+            __hip_atomic_store(mailbox, (int)gridDim.x + atomicAdd(a.counter, 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         // patch(k+1) early (needed at the top of the next step: between the transform's column
         // passes), W(k+1) between the MFMAs below
         if (stamp) stamps[1] = (int)__builtin_amdgcn_s_memtime();
@@ -309,7 +315,10 @@ wino43_f32_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         if (stamp) stamps[5] = (int)__builtin_amdgcn_s_memtime();
         ++k_stamp;
-        if (comp_ch == 0) q0 = s_ctrl[0];
+        // (the store above completed ahead of the barrier: s_waitcnt vmcnt(0); read it at the L2)
+        if (comp_ch == 0)
+            q0 = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         advance(pit, pch, true);
         advance(wit, wch, false);
     };
@@ -356,7 +365,7 @@ wino43_f32_kernel(const ConvArgs a) {
             // block's wave through LDS
             f32x4 bw = {0.f, 0.f, 0.f, 0.f};
             if (a.bneck_w) bw = *reinterpret_cast<const f32x4*>(a.bneck_w + c0);
-            float* const sDot = smem + 2 * Cfg::kBufFloats + 4 + tb * 256;     // [tile t][4 x 4 pixels]
+            float* const sDot = smem + Cfg::kPatchFloats + tb * 256;     // [tile t][4 x 4 pixels]
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 y[4];
@@ -414,7 +423,7 @@ wino43_f32_kernel(const ConvArgs a) {
             __syncthreads();
             if (cbw == 0 && g == 0) {
                 const Item it = decode(comp_item);
-                const float* sDot = smem + 2 * Cfg::kBufFloats + 4 + tb * 256;
+                const float* sDot = smem + Cfg::kPatchFloats + tb * 256;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
