@@ -401,7 +401,7 @@ def main():
         traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
         traffic_src = t['source']
     common = dict(traffic=traffic, traffic_unit='bytes/launch', traffic_source=traffic_src,
-                  kernel='wino43_f32_kernel (24 launches per step) + conv3x3_mfma_kernel (6 transposed convs) '
+                  kernel='wino43_f32_kernel (24 launches per step) + deconv3x3_f32_kernel (6 transposed convs) '
                          '+ 2 first-layer launches',
                   launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
                   algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
@@ -424,8 +424,8 @@ def main():
                         executed_frac=round(executed / 157.3, 4),
                         algorithm='Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 for the 3x3 '
                                   'stride-1 layers (fp32 throughout; 4x fewer multiplications than '
-                                  'the direct form priced by `achieved`), direct implicit GEMM for '
-                                  'the first layer and the transposed convs', **common)
+                                  'the direct form priced by `achieved`), an LDS-DMA staged direct kernel for the transposed '
+                                  'convs, direct implicit GEMM for the first layers', **common)
     elif args.conv_dtype == 'f32s':
         # split mode: three bf16 MFMAs per product term -> 3x the algorithmic FLOPs on the
         # bf16 pipe (2.5 PFLOP/s dense); the fp32-equivalent rate is given beside it
