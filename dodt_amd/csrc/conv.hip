@@ -80,19 +80,16 @@ const std::vector<KernelVariant>& variants() {
 
 // smallest padded pixel count wins; ties go to the larger output tile
 int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int parts, int batch,
-                 int num_cus, bool last) {
+                 int num_cus) {
     const auto& vs = variants();
     const bool small = Cin < dodt::kCK;
     int best = -1;
     double best_cost = 1e300;
-    // fp32 3x3 stride-1 convs with >= 4 chunks of input channels run as Winograd F(2x2,3x3)
-    // (2.25x fewer fp32 MFMA cycles).  DODT_CONV_WINO: 2 (default) = the 128-accumulator variant,
-    // two workgroups per CU (both stacks 3.0 ms against 4.8 ms for the direct kernels);
-    // 1 = the 256-accumulator variants, one workgroup per CU (no faster than direct: a lone
-    // wave per SIMD issues in order and nothing hides behind its MFMA bursts); 0 = direct.
-    // DODT_CONV_WINO: 4 (default) = F(4x4,3x3) (wino43_kernel.h) where it applies -- not the stack's
-    // last layer (NHWC output, fused bottleneck), which takes the F(2x2) kernel --, 2 = F(2x2,3x3)
-    // everywhere, 1 = its 256-accumulator variants, 0 = direct.
+    // fp32 3x3 stride-1 convs with >= 4 chunks of input channels run as Winograd.
+    // DODT_CONV_WINO: 4 (default) = F(4x4,3x3) (wino43_kernel.h: 4x fewer fp32 MFMA cycles than the
+    // direct form; both stacks 2.7 ms), 2 = F(2x2,3x3) with 128 accumulators, two workgroups per CU
+    // (wino_kernels.h: 3.0 ms), 1 = its 256-accumulator variants, one workgroup per CU (no faster
+    // than direct), 0 = the direct kernels (4.8 ms).
     static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 4;
     if (wino_mode > 0 && !deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
         for (size_t i = 0; i < vs.size(); ++i) {
@@ -607,8 +604,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         Layer l;
         l.name = name; l.deconv = deconv; l.H = h; l.W = w; l.Cin = cin; l.Cout = cout;
         l.src = src; l.src_coff = src_coff; l.dst = dst; l.dst_coff = dst_coff;
-        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, ex->parts, batch, ctx->num_cus,
-                                 std::string(name) == "pyramid_fusion1");
+        l.variant = pick_variant(deconv, h, w, cin, cout, bf16, ex->parts, batch, ctx->num_cus);
         l.real_cin = cin;
         ex->layers.push_back(l);
     };
