@@ -114,15 +114,26 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         for (size_t i = 0; i < vs.size(); ++i)
             if (vs[i].deconv_dma && vs[i].BN == want_bn && Cout % want_bn == 0) return (int)i;
     }
-    // DODT_CONV_BF16_DMA=1: bf16 3x3 stride-1 layers on the LDS-DMA staged kernel
-    // (conv_bf16_dma.h) instead of the template's bf16 instantiation.  Measured at parity
-    // (both stacks 1.24 ms against 1.27 ms): the bf16 layers are bound by the global -> LDS fill
-    // rate either way, so it is not the default.
-    static const bool bf16_dma = getenv("DODT_CONV_BF16_DMA") && atoi(getenv("DODT_CONV_BF16_DMA")) != 0;
+    // bf16 3x3 stride-1 layers: the LDS-DMA staged kernel (conv_bf16_dma.h: scalar-only copy issue
+    // between the MFMAs, accumulators pinned in place; stacks alone as fast as the template's bf16
+    // instantiation, frame-pair pipeline 7 % faster: 625 against 585 pairs/s).  DODT_CONV_BF16_DMA=0
+    // selects the template.
+    static const bool bf16_dma = !(getenv("DODT_CONV_BF16_DMA") && atoi(getenv("DODT_CONV_BF16_DMA")) == 0);
     if (bf16_dma && bf16 && parts == 1 && !deconv && Cin >= 32 && Cin % 32 == 0) {
-        for (size_t i = 0; i < vs.size(); ++i)
-            if (vs[i].dma && Cout % vs[i].BN == 0 && (best < 0 || vs[i].BN > vs[best].BN))
+        // the widest channel tile that still leaves four items per CU (two resident workgroups,
+        // two rounds): below that the CUs run one wave per SIMD or idle
+        for (size_t i = 0; i < vs.size(); ++i) {
+            if (!vs[i].dma || Cout % vs[i].BN != 0) continue;
+            const long n = (long)dodt::ceil_div(H, vs[i].TH) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch;
+            const bool enough = n >= 4L * num_cus;
+            if (best < 0) { best = (int)i; continue; }
+            const long nb = (long)dodt::ceil_div(H, vs[best].TH) * dodt::ceil_div(W, vs[best].TW) *
+                            (Cout / vs[best].BN) * batch;
+            const bool best_enough = nb >= 4L * num_cus;
+            if ((enough && !best_enough) || (enough == best_enough && (enough ? vs[i].BN > vs[best].BN
+                                                                              : vs[i].BN < vs[best].BN)))
                 best = (int)i;
+        }
         if (best >= 0) return best;
     }
     for (size_t i = 0; i < vs.size(); ++i) {

@@ -25,6 +25,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "conv_kernels.h"
 #include "wino_kernels.h"   // blds16, make_rsrc, kOob
 
@@ -58,7 +60,6 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // ring of S chunk images: [patch | weights] each
     int* s_ctrl = reinterpret_cast<int*>(smem + S * Cfg::kBufFloats);
-    float* const sDummy = smem + S * Cfg::kBufFloats + 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,21 +107,27 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
     __syncthreads();
     int cslot = 0, cch = 0;
     bool cur_live = true;            // the cursor points at a real chunk
-    auto copies = [&](int b) {
-        float* img = smem + b * Cfg::kBufFloats;
-#pragma unroll
-        for (int n = 0; n < Cfg::kPatchPerWave; ++n) {
+    // copy n of this wave for the cursor's chunk into image b; scalar operands only: the copies
+    // are issued between the MFMAs, where a vector instruction would wait for the SIMD's matrix
+    // work
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    const unsigned dummy_addr = lds0 + (S * Cfg::kBufFloats + 4) * 4;
+    const int w_voff = lane * 16;
+    auto copy_n = [&](int n, int b) {
+        const unsigned img = lds0 + (unsigned)(b * Cfg::kBufFloats) * 4;
+        if (n < Cfg::kPatchPerWave) {            // compile-time
             const int j = wave + 4 * n;
-            const bool real = j < Cfg::kPatchInstr;
-            blds16(in_rsrc, p_off[n], cch * plane_bytes, real ? img + j * 256 : sDummy);
-        }
-#pragma unroll
-        for (int n = 0; n < Cfg::kWPerWave; ++n) {
-            const int j = wave + 4 * n;
+            blds16s(in_rsrc, p_off[n], cch * plane_bytes, j < Cfg::kPatchInstr ? img + j * 1024 : dummy_addr);
+        } else {
+            const int j = wave + 4 * (n - Cfg::kPatchPerWave);
             const bool real = j < Cfg::kWInstr;
-            blds16(w_rsrc, real ? lane * 16 : kOob, cch * (Cfg::kWFloats * 4) + j * 1024,
-                   real ? img + Cfg::kPatchFloats + j * 256 : sDummy);
+            blds16s(w_rsrc, real ? w_voff : kOob, cch * (Cfg::kWFloats * 4) + j * 1024,
+                    real ? img + Cfg::kPatchFloats * 4 + j * 1024 : dummy_addr);
         }
+    };
+    auto copies = [&](int b) {
+#pragma unroll
+        for (int n = 0; n < Cfg::kCopies; ++n) copy_n(n, b);
     };
     auto advance = [&]() {
         if (!cur_live) return;
@@ -155,55 +162,90 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         copies(b);
         advance();
     }
-    // chunk 0 has landed once all but the newest (S - 2) chunks' copies are done
-    __builtin_amdgcn_s_waitcnt((0xc07f & ~0xc00f) | (((S - 2) * Cfg::kCopies) & 0xf) |
-                               ((((S - 2) * Cfg::kCopies) >> 4) << 14));
+    __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_s_barrier();
 
-    int ring = 0;                    // image of the chunk being computed
-    while (k0 < a.n_items) {
-        f32x16 acc[MT * NT];
+    static_assert(S == 2, "the chunk loop below is unrolled for two images");
+    // One step = the 9 MT NT MFMAs of chunk k from image PAR (accumulating in place in AGPRs: inline
+    // asm, see wino43_kernel.h) with the copies of chunk k+1 into image PAR ^ 1 issued one per
+    // tap in their shadow; patch rows of the next kx and weight fragments of the next tap are read
+    // one group ahead (pinned by scheduling barriers).
+    auto mfma_acc = [&](const f32x4& w, const f32x4& x, f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
+    };
+    auto mfma_first = [&](const f32x4& w, const f32x4& x, f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(w), "v"(x));
+    };
+    int k_stamp = 0;
+    auto step = [&](auto par, auto first, f32x16 (&acc)[MT * NT], int comp_ch) {
+        constexpr int PAR = decltype(par)::value;
+        constexpr bool FIRST = decltype(first)::value;
+        // (a.debug & 32, tools/: s_memtime stamps of one wave's first 12 steps, counter_base[32..])
+        const bool stamp = (a.debug & 32) && blockIdx.x == 1 && tid == 0 && k_stamp < 12;
+        int* stamps = a.counter_base + 32 + (k_stamp < 12 ? k_stamp : 0) * 6;
+        if (stamp) { stamps[0] = (int)__builtin_amdgcn_s_memtime(); stamps[1] = stamps[0]; stamps[2] = stamps[0]; }
+        if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+        const float* sP = smem + PAR * Cfg::kBufFloats + row0;
+        const float* sW = smem + PAR * Cfg::kBufFloats + Cfg::kPatchFloats + w_lane;
+        f32x4 x[MT + 2], w[2][NT];
 #pragma unroll
-        for (int k = 0; k < MT * NT; ++k)
+        for (int r = 0; r < MT + 2; ++r)
+            x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-        for (int comp_ch = 0; comp_ch < nchunks; ++comp_ch) {
-            if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
-            // copies of chunk (k + S - 1) into the image chunk k - 1 used (free since the barrier)
-            int wr = ring + S - 1;
-            if (wr >= S) wr -= S;
-            copies(wr);
-            const float* sP = smem + ring * Cfg::kBufFloats + row0;
-            const float* sW = smem + ring * Cfg::kBufFloats + Cfg::kPatchFloats + w_lane;
+        for (int nt = 0; nt < NT; ++nt) w[0][nt] = *reinterpret_cast<const f32x4*>(sW + nt * 32 * 4);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                f32x4 x[MT + 2];
+        for (int g9 = 0; g9 < 9; ++g9) {             // group g9 = kx * 3 + ky
+            const int kx = g9 / 3, ky = g9 % 3;
+            if (g9 + 1 < 9) {
+                const int kx1 = (g9 + 1) / 3, ky1 = (g9 + 1) % 3;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    w[(g9 + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(
+                        sW + ((ky1 * 3 + kx1) * 2 * BN + nt * 32) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (FIRST && g9 == 0) mfma_first(w[g9 & 1][nt], x[mt + ky], acc[mt * NT + nt]);
+                    else mfma_acc(w[g9 & 1][nt], x[mt + ky], acc[mt * NT + nt]);
+                }
+            if (ky == 2 && kx < 2) {     // the next kx's rows (the partner wave covers their latency)
 #pragma unroll
                 for (int r = 0; r < MT + 2; ++r)
-                    x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[kx]);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    f32x4 w[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        w[nt] = *reinterpret_cast<const f32x4*>(
-                            sW + ((ky * 3 + kx) * 2 * BN + nt * 32) * 4);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt * NT + nt] = mfma_bf16(w[nt], x[mt + ky], acc[mt * NT + nt]);
-                }
+                    x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[kx + 1]);
             }
-            // the next chunk has landed once all but the newest (S - 2) chunks' copies are done
-            // (vmcnt is in issue order; an epilogue's stores are older than those copies)
-            __builtin_amdgcn_s_waitcnt((0xc07f & ~0xc00f) | (((S - 2) * Cfg::kCopies) & 0xf) |
-                                       ((((S - 2) * Cfg::kCopies) >> 4) << 14));
-            __builtin_amdgcn_s_barrier();
-            if (comp_ch == 0) k2 = s_ctrl[0];     // the item claimed in this step: third in line
-            advance();
-            if (++ring == S) ring = 0;
+            if (g9 < Cfg::kCopies) copy_n(g9, PAR ^ 1);
+            if (g9 == 8) {
+#pragma unroll
+                for (int n = 9; n < Cfg::kCopies; ++n) copy_n(n, PAR ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0);        // the copies of chunk k+1 have landed
+        if (stamp) stamps[4] = (int)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        if (stamp) stamps[5] = (int)__builtin_amdgcn_s_memtime();
+        ++k_stamp;
+        if (comp_ch == 0) k2 = s_ctrl[0];     // the item claimed in this step: third in line
+        advance();
+    };
+    while (k0 < a.n_items) {
+        f32x16 acc[MT * NT];
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        step(T0{}, std::true_type{}, acc, 0);
+        step(T1{}, std::false_type{}, acc, 1);
+        for (int comp_ch = 2; comp_ch < nchunks; comp_ch += 2) {      // Cin / 16 is even
+            step(T0{}, std::false_type{}, acc, comp_ch);
+            step(T1{}, std::false_type{}, acc, comp_ch + 1);
+        }
+        // the asm MFMAs are opaque to the hazard recogniser: 16-pass results need 18 wait states
+#pragma unroll
+        for (int k = 0; k < MT * NT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
         // ---- epilogue (as in conv3x3_mfma_kernel): BN + ReLU, stores, fused pool / bottleneck ---
         const Item cur = decode(k0);
         float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
@@ -227,6 +269,8 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
                 else
                     store_tile<false, true, false>(a, out, acc[mt * NT + nt], c0, lh, y - a.out_y0,
                                                    x, a.W, plane, ok, cur.frame);
+                // one accumulator tile at a time: they live in AGPRs and pass through VGPRs here
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (pool) {
@@ -237,8 +281,11 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
                 const bool ok = y < a.H && x < a.W;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
+                {
                     pool_tile<32, true, true, false>(a, acc[mt * NT + nt], acc[(mt + 1) * NT + nt],
                                                      cur.ntile * BN + nt * 32, lh, y, x, cur.frame, ok);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // next item: the queue moves up, the cursor's slot with it

@@ -73,16 +73,17 @@ def test_bf16_is_opt_in_and_checked():
     assert ex._bf16 is False
 
 
-def test_lds_dma_bf16_kernel_matches_the_same_bars():
-    """DODT_CONV_BF16_DMA=1 selects conv_bf16_dma.h (LDS-DMA staging, row-sliding fragment
-    reuse) for the 3x3 stride-1 layers; the library reads the switch once per process, so the
-    bf16 all-layers check runs in a child process with it."""
+def test_template_bf16_kernel_matches_the_same_bars():
+    """The 3x3 stride-1 bf16 layers run on conv_bf16_dma.h by default (LDS-DMA staging,
+    row-sliding fragment reuse; every other test of this file).  DODT_CONV_BF16_DMA=0 selects the
+    fp32 kernel template's bf16 instantiation instead; the library reads the switch once per
+    process, so the bf16 all-layers check runs in a child process with it."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DODT_CONV_BF16_DMA='1')
+    env = dict(os.environ, DODT_CONV_BF16_DMA='0')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-q',
-                        '-x', '-k', 'not lds_dma'], env=env, cwd=root, capture_output=True,
+                        '-x', '-k', 'not template_bf16'], env=env, cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
