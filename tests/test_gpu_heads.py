@@ -66,7 +66,9 @@ def test_correlation_full_size_properties(ctx):
     (1024, 1568, 2048, True, True),    # stage-2 fc6 with mean fusion
     (1000, 2048, 10, False, False),    # off_out
     (513, 1225, 2048, True, False),    # corr fc6: K not a multiple of 4
-    (1, 40, 3, False, False), (64, 32, 128, True, False)])
+    (1, 40, 3, False, False), (64, 32, 128, True, False),
+    # the LDS-DMA staged kernel (K % 32 == 0, 128-wide blocking): ragged M, two-stage K, fusion
+    (1000, 2048, 2048, True, False), (130, 64, 128, False, False), (513, 96, 256, True, True)])
 def test_fully_connected_matches_oracle(ctx, M, K, N, relu, fuse):
     rng = np.random.default_rng(M + K + N)
     x = rng.normal(size=(M, K)).astype(np.float32)
