@@ -313,12 +313,15 @@ int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
 //     running fastest: its workgroups share x rows and sweep K together, so most fills hit its L2
 //     (fill rate from L2 ~50 B/clk/CU against ~10.5 from beyond it, tools/micro/fill_rate.hip).
 // Needs K % 32 == 0, ldx % 4 == 0 (16-byte aligned rows) and the 128-wide weight blocking.
-constexpr int kDmaBM = 64, kDmaBN = 64, kDmaBK = 32, kDmaStages = 3;
-constexpr int kDmaXFloats = kDmaBM * kDmaBK, kDmaWFloats = kDmaBK * kDmaBN;
+constexpr int kDmaBM = 64, kDmaBK = 32, kDmaStages = 3;
+constexpr int kDmaXFloats = kDmaBM * kDmaBK;
 
-template <bool FUSE>
+// NT: 32x32 MFMA tiles per wave along N (tile 64 x 64 NT): 2 when M is large enough for 64 x 128 tiles
+// to fill two workgroups per CU (both frames' proposals in one launch), else 1.
+template <bool FUSE, int NT>
 __global__ void __launch_bounds__(256, 2)
 fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int kDmaBN = 64 * NT, kDmaWFloats = kDmaBK * kDmaBN;
     using dodt::blds16;
     using dodt::i32x4_t;
     using dodt::kOob;
@@ -350,13 +353,17 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     const int n0 = nt0 * kDmaBN;
     const float* wblk = a.w + ((size_t)(n0 / 128) * (a.Kp / 8) * 2 * 128 + (n0 % 128)) * 4;
     const i32x4_t w_rsrc = make_rsrc(wblk, (unsigned)(((size_t)(a.Kp / 8) * 2 * 128 - (n0 % 128)) * 16));
-    int x_off[2], w_off[2];
+    int x_off[2], w_off[2 * NT];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int piece = wave + 4 * k;                  // 0 .. 7
         const int row = piece * 8 + (lane >> 3), cq = (lane & 7) ^ ((row >> 1) & 7);
         x_off[k] = row < rows ? (row * a.ldx + cq * 4) * 4 : kOob;
-        w_off[k] = (piece * 128 + lane) * 16;            // (q, h) = piece: row of 128 features
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) {
+        const int piece = wave + 4 * k;                  // 0 .. 8 NT - 1: (q, h) row and 64-feature half
+        w_off[k] = ((piece / NT) * 128 + (piece % NT) * 64 + lane) * 16;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
     auto issue = [&](int st, int buf) {       // scalar arithmetic only (see blds16s)
@@ -366,20 +373,25 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
             const unsigned piece = (unsigned)(wave + 4 * k) * 1024;
             dodt::blds16s(x_rsrc, x_off[k], st * (kDmaBK * 4), sX + piece);
             if (FUSE) dodt::blds16s(x2_rsrc, x_off[k], st * (kDmaBK * 4), sX + kDmaXFloats * 4 + piece);
-            dodt::blds16s(w_rsrc, w_off[k], st * (8 * 128 * 16), sX + kDmaXFloats * (FUSE ? 8 : 4) + piece);
         }
-    };
-    constexpr int kPerStage = FUSE ? 6 : 4;              // copies per wave and stage
-
-    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int k = 0; k < 2 * NT; ++k)
+            dodt::blds16s(w_rsrc, w_off[k], st * (8 * 128 * 16),
+                          sX + kDmaXFloats * (FUSE ? 8 : 4) + (unsigned)(wave + 4 * k) * 1024);
+    };
+    constexpr int kPerStage = (FUSE ? 4 : 2) + 2 * NT;   // copies per wave and stage
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
     // fragment addresses inside a stage: x row (wm * 32 + li), k-quad 2 q + lh, swizzled;
     // weights row (2 q + lh), feature wn * 32 + li
     const int xrow = wm * 32 + li;
     const int xsw = (xrow >> 1) & 7;
     const int x_base = xrow * kDmaBK;
-    const int w_base = kDmaXFloats * (FUSE ? 2 : 1) + (lh * kDmaBN + wn * 32 + li) * 4;
+    const int w_base = kDmaXFloats * (FUSE ? 2 : 1) + (lh * kDmaBN + wn * 32 * NT + li) * 4;
 
     // per-lane fragment offsets inside a stage (floats): with the buffer number a compile-time
     // constant (ring walked by an unrolled-by-three loop) every LDS read is base + immediate
@@ -394,11 +406,13 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
         __builtin_amdgcn_s_barrier();     // ... for every wave; buffer (BUF + 2) % 3 is free
         if (st + 2 < nstages) issue(st + 2, (BUF + 2) % kDmaStages);
         const float* sS = smem + BUF * kStage;
-        f32x4 xf[4], wf[4];
+        f32x4 xf[4], wf[4][NT];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             xf[q] = *reinterpret_cast<const f32x4*>(sS + xo[q]);
-            wf[q] = *reinterpret_cast<const f32x4*>(sS + w_base + q * (2 * kDmaBN * 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[q][nt] = *reinterpret_cast<const f32x4*>(sS + w_base + q * (2 * kDmaBN * 4) + nt * 128);
         }
         f32x4 x2[FUSE ? 4 : 1];
         if (FUSE) {
@@ -416,7 +430,9 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[q][s2], wf[q][s2], acc, 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[q][s2], wf[q][nt][s2], acc[nt], 0, 0, 0);
     };
     issue(0, 0);
     if (nstages > 1) issue(1, 1);
@@ -426,21 +442,28 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
         if (st + 2 < nstages) stage(std::integral_constant<int, 2>{}, st + 2);
     }
     // epilogue: bias + activation; lane = feature, registers = samples
-    const int n = n0 + wn * 32 + li;
-    const float b = a.bias[n];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && n < a.N) {
-            float v = acc[r] + b;
-            if (a.relu) v = fmaxf(v, 0.0f);
-            a.y[(size_t)m * a.ldy + n] = v;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * 32 * NT + nt * 32 + li;
+        const float b = a.bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < M && n < a.N) {
+                float v = acc[nt][r] + b;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                a.y[(size_t)m * a.ldy + n] = v;
+            }
         }
     }
 }
 
 int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
-    const int tiles_m = dodt::ceil_div(a.M, kDmaBM), tiles_n = Npad / kDmaBN;
+    // 64 x 128 tiles (two MFMA tiles per wave) when that still gives two workgroups per CU
+    static const int force_nt = getenv("DODT_FC_NT") ? atoi(getenv("DODT_FC_NT")) : 0;
+    const int nt = force_nt ? force_nt
+                            : (!a.x2 && (long)dodt::ceil_div(a.M, kDmaBM) * (Npad / 128) >= 2 * 256 ? 2 : 1);
+    const int tiles_m = dodt::ceil_div(a.M, kDmaBM), tiles_n = Npad / (64 * nt);
     auto go = [&](auto kernel, size_t lds) -> hipError_t {
         static std::mutex mu;
         static std::set<const void*> prepared;
@@ -457,8 +480,9 @@ int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
         return hipSuccess;
     };
     hipError_t e;
-    if (a.x2) e = go(&fc_dma_kernel<true>, (size_t)kDmaStages * (2 * kDmaXFloats + kDmaWFloats) * 4);
-    else e = go(&fc_dma_kernel<false>, (size_t)kDmaStages * (kDmaXFloats + kDmaWFloats) * 4);
+    if (a.x2) e = go(&fc_dma_kernel<true, 1>, (size_t)kDmaStages * (2 * kDmaXFloats + kDmaBK * 64) * 4);
+    else if (nt == 2) e = go(&fc_dma_kernel<false, 2>, (size_t)kDmaStages * (kDmaXFloats + kDmaBK * 128) * 4);
+    else e = go(&fc_dma_kernel<false, 1>, (size_t)kDmaStages * (kDmaXFloats + kDmaBK * 64) * 4);
     DODT_HIP_CHECK(e);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
