@@ -368,7 +368,7 @@ class FramePairPipeline(object):
             ops.crop_and_resize(c, bneck_i, img_hw + (1,), b['img_norm'], A, None,
                                 (3, 3), b['rpn_img_roi'])
             self._mark(c, st['step'], 'tail%d_crops' % f)
-            if computed:
+            if computed and not os.environ.get('DODT_PIPE_NO_RPN'):      # (tools/: timing experiment)
                 self.rpn_head.forward(c, b['rpn_bev_roi'], b['rpn_img_roi'], A, b['rpn_logits'],
                                       b['rpn_offsets'], scratch['rpn'])
             self._mark(c, st['step'], 'tail%d_rpn' % f)
