@@ -33,7 +33,7 @@ def _check_all_layers(ex, params, x, pad_top):
         _close(ex.activation(name), np.stack(collect[name]), name)
 
 
-@pytest.mark.parametrize('h,w', [(60, 96), (28, 40)])
+@pytest.mark.parametrize('h,w', [(60, 96), (28, 40), (44, 72), (12, 136)])
 def test_bev_pyramid_small_all_layers(h, w):
     """(h + 4) x w must be divisible by 8; every layer is compared."""
     rng = np.random.default_rng(h * w)
