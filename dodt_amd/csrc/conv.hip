@@ -121,18 +121,17 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     static const bool bf16_dma = !(getenv("DODT_CONV_BF16_DMA") && atoi(getenv("DODT_CONV_BF16_DMA")) == 0);
     if (bf16_dma && bf16 && parts == 1 && !deconv && Cin >= 32 && Cin % 32 == 0) {
         // the widest channel tile that still leaves four items per CU (two resident workgroups,
-        // two rounds): below that the CUs run one wave per SIMD or idle
+        // two rounds); if none does, the one with the most items (half-height tiles were tried for
+        // the small maps: slower, the per-item cost grows faster than the balance improves)
+        long best_n = 0;
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].dma || Cout % vs[i].BN != 0) continue;
             const long n = (long)dodt::ceil_div(H, vs[i].TH) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch;
-            const bool enough = n >= 4L * num_cus;
-            if (best < 0) { best = (int)i; continue; }
-            const long nb = (long)dodt::ceil_div(H, vs[best].TH) * dodt::ceil_div(W, vs[best].TW) *
-                            (Cout / vs[best].BN) * batch;
-            const bool best_enough = nb >= 4L * num_cus;
-            if ((enough && !best_enough) || (enough == best_enough && (enough ? vs[i].BN > vs[best].BN
-                                                                              : vs[i].BN < vs[best].BN)))
-                best = (int)i;
+            const bool enough = n >= 4L * num_cus, best_enough = best_n >= 4L * num_cus;
+            if (best < 0 || (enough && !best_enough) || (enough && best_enough && vs[i].BN > vs[best].BN) ||
+                (!enough && !best_enough && n > best_n)) {
+                best = (int)i; best_n = n;
+            }
         }
         if (best >= 0) return best;
     }
@@ -425,6 +424,29 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
             fprintf(stderr, "[dodt]   steps 0..11: %d stamp ticks in %d ticks of the 100 MHz clock (%.0f MHz)\n",
                     h[66] - h[0], h[73] - h[72], 100.0 * (h[66] - h[0]) / (h[73] - h[72]));
     }
+    if ((a.debug & 128) && v.dma) {   // diagnostic: when the workgroups of this launch started and ended
+        std::vector<int> h(4 * grid_x);
+        (void)hipStreamSynchronize(ex->ctx->stream);
+        (void)hipMemcpy(h.data(), ex->d_counters + 64 + 256, h.size() * sizeof(int), hipMemcpyDeviceToHost);
+        int t0 = h[0], s_max = h[0], f_max = h[1], e_min = h[2], e_max = h[2], items[8] = {};
+        double first_sum = 0, run_sum = 0;
+        for (int b = 0; b < (int)grid_x; ++b) {
+            t0 = std::min(t0, h[4 * b]); s_max = std::max(s_max, h[4 * b]);
+            f_max = std::max(f_max, h[4 * b + 1]);
+            e_min = std::min(e_min, h[4 * b + 2]); e_max = std::max(e_max, h[4 * b + 2]);
+            items[std::min(h[4 * b + 3], 7)]++;
+            first_sum += (h[4 * b + 1] - h[4 * b]) / 100.0;
+            run_sum += (h[4 * b + 2] - h[4 * b + 1]) / 100.0 / std::max(h[4 * b + 3], 1);
+        }
+        fprintf(stderr, "[dodt] %-16s %4d wgs, %5d items x %d chunks: last start +%.2f us, last first-step +%.2f, first end +%.2f, "
+                "last end +%.2f; mean start->first step %.2f us, mean per item %.2f us; wgs by item count:",
+                l.name.c_str(), (int)grid_x, a.n_items, a.Cin / 16, (s_max - t0) / 100.0, (f_max - t0) / 100.0,
+                (e_min - t0) / 100.0, (e_max - t0) / 100.0, first_sum / grid_x, run_sum / grid_x);
+        for (int k = 0; k < 8; ++k) if (items[k]) fprintf(stderr, " %d:%d", k, items[k]);
+        int mt[2] = {0, 0};
+        (void)hipMemcpy(mt, ex->d_counters + 64 + 250, sizeof(mt), hipMemcpyDeviceToHost);
+        fprintf(stderr, "; shader clock of workgroup 1: %.2f GHz\n", (mt[1] - mt[0]) / ((h[4 + 2] - h[4 + 0]) * 10.0));
+    }
     if (a.debug & 8) {   // diagnostic: print the in-kernel clock of this launch
         unsigned long long h[2] = {0, 0};
         (void)hipStreamSynchronize(ex->ctx->stream);
@@ -602,8 +624,8 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
             return DODT_ERR_HIP;
         }
     }
-    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 2048 * sizeof(int)));
-    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 2048 * sizeof(int), ctx->stream));
+    DODT_HIP_CHECK(hipMalloc(&ex->d_counters, 4096 * sizeof(int)));
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 4096 * sizeof(int), ctx->stream));
     DODT_HIP_CHECK(hipMalloc(&ex->d_zeros, 256));
     DODT_HIP_CHECK(hipMemsetAsync(ex->d_zeros, 0, 256, ctx->stream));
     // the pad rows of X0 stay zero for the life of the extractor

@@ -101,10 +101,19 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
     // the copy cursor, which runs S - 1 <= 3 chunks = at most two items ahead of the MFMAs).
     int k0 = blockIdx.x, k1 = a.n_items, k2 = a.n_items;
     if (k0 >= a.n_items) return;
-    if (tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
-    __syncthreads();
-    k1 = s_ctrl[0];
-    __syncthreads();
+    // the successor's ticket is drawn now and read behind the prologue's copies (one barrier, and
+    // the atomic's round trip hides behind the first fills)
+    int pend = 0;
+    if (tid == 0) pend = atomicAdd(a.counter, 1);
+    // (a.debug & 128, tools/: start | first step | end on the chip-wide 100 MHz clock and the item
+    //  count of every workgroup, 4 words each from counter_base[256])
+    const bool wgstamp = (a.debug & 128) && tid == 0;
+    int* wgs = a.counter_base + 256 + 4 * blockIdx.x;
+    int n_done = 0;
+    if (wgstamp) {
+        wgs[0] = (int)__builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 1) a.counter_base[250] = (int)__builtin_amdgcn_s_memtime();
+    }
     int cslot = 0, cch = 0;
     bool cur_live = true;            // the cursor points at a real chunk
     // copy n of this wave for the cursor's chunk into image b; scalar operands only: the copies
@@ -162,8 +171,11 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         copies(b);
         advance();
     }
+    if (tid == 0) s_ctrl[1] = (int)gridDim.x + pend;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_s_barrier();
+    k1 = s_ctrl[1];           // (word 1: word 0 is rewritten by thread 0 at the top of step 0)
+    if (wgstamp) wgs[1] = (int)__builtin_amdgcn_s_memrealtime();
 
     static_assert(S == 2, "the chunk loop below is unrolled for two images");
     // One step = the 9 MT NT MFMAs of chunk k from image PAR (accumulating in place in AGPRs: inline
@@ -293,6 +305,12 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         k1 = k2;
         k2 = a.n_items;
         --cslot;
+        ++n_done;
+    }
+    if (wgstamp) {
+        wgs[2] = (int)__builtin_amdgcn_s_memrealtime();
+        wgs[3] = n_done;
+        if (blockIdx.x == 1) a.counter_base[251] = (int)__builtin_amdgcn_s_memtime();
     }
 }
 
