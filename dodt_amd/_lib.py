@@ -122,7 +122,17 @@ SIGNATURES = {
     'dodt_angle_vector_to_orientation': (_i, [_vp, _pf, _i, _pi32, _pf]),
     'dodt_box_4c_decode': (_i, [_vp, _pf, _pf, _i, _pi32, C.POINTER(_f),
                                 C.POINTER(_f), _pf, _pf, _pf]),
+    'dodt_comm_unique_id': (_i, [_vp]),
+    'dodt_comm_create': (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    'dodt_comm_destroy': (_i, [_vp]),
+    'dodt_comm_rank': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'dodt_all_gather_records': (_i, [_vp, _vp, _i, _pf, _pi32, _i, _i, _i, _i, _pf, _pi32]),
+    'dodt_comm_join': (_i, [_vp, _i, _vp]),
+    'dodt_comm_sync': (_i, [_vp]),
+    'dodt_comm_barrier': (_i, [_vp]),
+    'dodt_comm_max_f64': (_i, [_vp, C.POINTER(_d)]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -4,9 +4,15 @@ Frame pairs are independent through NMS #2 (batch size 1, no cross-pair state:
 avod/core/models/dt_rpn_model.py:733-735), so they shard round-robin over ranks with
 no data-path collective; the only exchange is an all-gather of the fixed-size
 detection records, which the sequential temporal module consumes
-(avod/core/dt_evaluator_utils.py:212-367).  torch.distributed is used as plumbing
-(backend "nccl" = RCCL on the GPUs, "gloo" in the CPU tests).
+(avod/core/dt_evaluator_utils.py:212-367).  On the GPUs the exchange is `Communicator`:
+RCCL through the C-ABI (dodt_comm_* / dodt_all_gather_records, include/dodt_hip.h), no PyTorch;
+the assignment and merge logic below is backend-free and is also exercised over
+torch.distributed's gloo backend in the CPU tests (`all_gather_records`).
 """
+import ctypes as C
+import os
+import time
+
 import numpy as np
 
 MAX_DET = 100
@@ -31,6 +37,93 @@ def all_gather_records(dist, rec, cnt, gathered, gathered_cnt):
     both the gloo and the nccl/RCCL backends accept)."""
     dist.all_gather_into_tensor(gathered, rec)
     dist.all_gather_into_tensor(gathered_cnt, cnt)
+
+
+class Communicator(object):
+    """One rank's RCCL communicator over the C-ABI.  `ctx`: the rank's device.Context.
+
+    The ncclUniqueId travels through a file: rank 0 writes `<id_path>` atomically, the others
+    poll for it (`rendezvous_path()` derives a per-job path from MASTER_PORT / the launcher's run
+    id, so that concurrent jobs on one host do not meet)."""
+
+    SLOTS = 4
+
+    def __init__(self, ctx, rank, world, id_path=None, timeout_s=120.0):
+        from dodt_amd import _lib
+        self._lib, self.lib, self.ctx = _lib, ctx.lib, ctx
+        self.rank, self.world = int(rank), int(world)
+        uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        path = id_path or rendezvous_path()
+        if self.rank == 0:
+            _lib.check(self.lib.dodt_comm_unique_id(uid), 'dodt_comm_unique_id')
+            if self.world > 1:
+                tmp = '%s.%d.tmp' % (path, os.getpid())
+                with open(tmp, 'wb') as fh:
+                    fh.write(bytes(uid))
+                os.replace(tmp, path)
+        else:
+            t0 = time.time()
+            while not (os.path.exists(path) and os.path.getsize(path) == _lib.COMM_ID_BYTES):
+                if time.time() - t0 > timeout_s:
+                    raise _lib.DodtError('rank %d: no RCCL id at %s after %.0f s'
+                                         % (self.rank, path, timeout_s))
+                time.sleep(0.01)
+            uid = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(open(path, 'rb').read())
+        h = C.c_void_p()
+        _lib.check(self.lib.dodt_comm_create(ctx.handle, self.rank, self.world, uid, C.byref(h)),
+                   'dodt_comm_create')
+        self.handle = h
+        self._id_path = path if (self.rank == 0 and self.world > 1) else None
+
+    def all_gather_records(self, producer, slot, d_rec, d_cnt, d_all_rec, d_all_cnt):
+        """Enqueue the step's exchange on the communicator's side stream, behind what
+        `producer` has enqueued so far.  d_rec (pairs, frames, MAX_DET, REC_COLS) float32 and
+        d_cnt (pairs, frames) int32 device arrays; d_all_* their (world * pairs, ...) twins."""
+        pairs, frames, max_det, cols = d_rec.shape
+        if tuple(d_all_rec.shape) != (self.world * pairs, frames, max_det, cols) or \
+                tuple(d_cnt.shape) != (pairs, frames) or \
+                tuple(d_all_cnt.shape) != (self.world * pairs, frames):
+            raise ValueError('all_gather_records: buffer shapes do not match the world size')
+        self._lib.check(self.lib.dodt_all_gather_records(
+            self.handle, producer.handle, int(slot), d_rec.ptr, d_cnt.ptr, pairs, frames, max_det,
+            cols, d_all_rec.ptr, d_all_cnt.ptr), 'dodt_all_gather_records')
+
+    def join(self, slot, consumer):
+        """`consumer`'s later work waits for the gather last enqueued with `slot`."""
+        self._lib.check(self.lib.dodt_comm_join(self.handle, int(slot), consumer.handle),
+                        'dodt_comm_join')
+
+    def sync(self):
+        self._lib.check(self.lib.dodt_comm_sync(self.handle), 'dodt_comm_sync')
+
+    def barrier(self):
+        self._lib.check(self.lib.dodt_comm_barrier(self.handle), 'dodt_comm_barrier')
+
+    def max_over_ranks(self, value):
+        v = C.c_double(float(value))
+        self._lib.check(self.lib.dodt_comm_max_f64(self.handle, C.byref(v)), 'dodt_comm_max_f64')
+        return v.value
+
+    def close(self):
+        if self.handle:
+            self.lib.dodt_comm_destroy(self.handle)
+            self.handle = None
+        if self._id_path:
+            try:
+                os.remove(self._id_path)
+            except OSError:
+                pass
+
+
+def rendezvous_path(env=None):
+    """Where the ranks of one job meet: keyed by the launcher's rendezvous port and by the
+    launcher's process id (the ranks of one node are children of one launcher -- torch.distributed.run's
+    agent or bench.py's own spawner --, so a file left behind by a crashed job is not picked up
+    by the next one; DODT_RUN_ID overrides the latter)."""
+    env = os.environ if env is None else env
+    key = '%s_%s' % (env.get('MASTER_PORT', '0'), env.get('DODT_RUN_ID') or os.getppid())
+    key = ''.join(ch if ch.isalnum() or ch in '_-' else '_' for ch in key)
+    return os.path.join(env.get('TMPDIR', '/tmp'), 'dodt_rccl_id_%s' % key)
 
 
 def merge_step(gathered, gathered_cnt, step, pairs_per_step, world):

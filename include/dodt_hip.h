@@ -356,6 +356,41 @@ int dodt_box_4c_decode(dodt_ctx* ctx, const float* d_top_anchors, const float* d
                        const float bev_extents[4], float* d_boxes_3d_out,
                        float* d_pred_anchors_out, float* d_bev_tf_out);
 
+/* ---- (e) multi-GPU: the one exchange step of the path, RCCL over xGMI, no PyTorch -----------
+ * The reference runs on ONE device (avod/experiments/run_tracking_inference.py:109-128 sets a
+ * single CUDA_VISIBLE_DEVICES and walks the sequences in a loop), so there is no reference
+ * collective to replace: frame pairs shard over ranks (pair i -> rank i mod N) and the
+ * sequential temporal module (avod/core/dt_evaluator_utils.py:189-362) needs every rank's detection
+ * records in sequence order.  One process per GPU; librccl.so is dlopen'ed by the first of these
+ * calls (a single-GPU process never maps it).
+ *   id          DODT_COMM_ID_BYTES opaque bytes (an ncclUniqueId) made by ONE rank with
+ *               dodt_comm_unique_id and handed to the others by the launcher's means (a file, an
+ *               environment variable, a socket: dodt_amd/sharding.py uses a file next to the
+ *               rendezvous port).
+ *   create      ncclCommInitRank on ctx's device + a side stream that every collective runs on.
+ *   all_gather  waits (event) for what `producer` has enqueued so far, then gathers
+ *               float32 [pairs][frames][max_det][cols] + int32 [pairs][frames] of every rank into
+ *               d_all_records / d_all_counts ([world][pairs]...; rank major) in one RCCL group, and
+ *               signals `slot`'s event (slots 0..3: the caller's ring of send buffers).  The
+ *               producer's stream is NOT made to wait: call dodt_comm_join(comm, slot, consumer)
+ *               on the context that is about to overwrite that slot's send buffer or read the
+ *               gathered data on the device, dodt_comm_sync for the host.
+ *   barrier     all ranks have arrived (and the side stream is drained);
+ *   max_f64     *value = max over ranks (the bench's max-over-ranks timing). */
+typedef struct dodt_comm dodt_comm;
+#define DODT_COMM_ID_BYTES 128
+int dodt_comm_unique_id(uint8_t* id_out);
+int dodt_comm_create(dodt_ctx* ctx, int rank, int world, const uint8_t* id, dodt_comm** out);
+int dodt_comm_destroy(dodt_comm* comm);
+int dodt_comm_rank(const dodt_comm* comm, int* rank, int* world);
+int dodt_all_gather_records(dodt_comm* comm, dodt_ctx* producer, int slot, const float* d_records,
+                            const int32_t* d_counts, int pairs, int frames, int max_det, int cols,
+                            float* d_all_records, int32_t* d_all_counts);
+int dodt_comm_join(dodt_comm* comm, int slot, dodt_ctx* consumer);
+int dodt_comm_sync(dodt_comm* comm);
+int dodt_comm_barrier(dodt_comm* comm);
+int dodt_comm_max_f64(dodt_comm* comm, double* value);
+
 #ifdef __cplusplus
 }
 #endif
