@@ -2,13 +2,16 @@
 """bench.py -- frame-pairs/sec of the DODT hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  (N > 1: one rank per GPU -- started by torch.distributed.run, which only serves as the process
+   launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are read from the environment), or by
+   this script itself when it is run by hand)
 
 One step = one pass of the hot path over one synthetic KITTI-shaped frame pair
 (2 x 120k points + 2 x 1242x375 RGB, tau = 2) whose inputs are already resident
 in HBM.  Frame pairs shard across ranks (pair i -> rank i mod N, weak scaling);
-after each step the ranks all-gather their detection records (RCCL).  Rank 0
-prints ONE JSON line.
+after each step the ranks all-gather their detection records with RCCL through the
+package's own C-ABI (dodt_comm_*, include/dodt_hip.h) on a side stream.  No PyTorch is
+imported.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -46,6 +49,9 @@ def parse():
     ap.add_argument('--no-alt', action='store_true',
                     help='skip the short extra run with the other conv arithmetic')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--comm', action='store_true',
+                    help='make an RCCL communicator even with one rank (exercises the exchange '
+                         'step on a single GPU)')
     ap.add_argument('--cpu-pairs', type=int, default=2,
                     help='frame pairs (= pool workers) of the CPU baseline sample')
     return ap.parse_args()
@@ -152,20 +158,52 @@ def cpu_baseline(computed_heads=True, pairs=2):
                             'pool_workers': cores, 'unit': 'frames/s'})
 
 
+FP32_MFMA_PEAK = 157.3     # TFLOP/s dense, MI355X_MICROARCH.md chip table (v_mfma_f32_*_f32)
+BF16_MFMA_PEAK = 2500.0    # TFLOP/s dense
+HBM_PEAK = 8000.0          # GB/s
+
+
+def _spawn_ranks(args):
+    """Started by hand with --gpus N and no launcher: run the ranks as plain child processes
+    (nothing has touched the GPU in this one) and leave with the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DODT_RUN_ID=str(os.getpid()))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    return max(p.wait() for p in procs)
+
+
+def _group_by_kernel(layers):
+    """Per-kernel totals of a list of per-layer measurements (dicts of forward_timed)."""
+    out = {}
+    for l in layers:
+        k = out.setdefault(l['kernel'], dict(kernel=l['kernel'], launches=0, ms=0.0, flops_executed=0.0,
+                                             flops_direct=0.0, bytes=0.0, layers=[]))
+        k['launches'] += l['launches']
+        k['ms'] += l['ms']
+        k['flops_executed'] += l['flops_executed']
+        k['flops_direct'] += l['flops_direct']
+        k['bytes'] += l['bytes']
+        k['layers'].append(l['name'])
+    return out
+
+
+def _profile_json(name):
+    path = os.path.join(ROOT, 'profiles', name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        # started by hand without a launcher: run the ranks as children (nothing has touched
-        # the GPU yet in this process) and leave with their exit code
-        import socket
-        import subprocess
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-               '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        raise SystemExit(_spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -174,27 +212,23 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         # first, while the GPU is still untouched: the workers are spawned processes
         baseline = cpu_baseline(args.heads == 'computed', args.cpu_pairs)
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path')
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    from dodt_amd import config, device, sharding, synth
-    from dodt_amd.pipeline import FramePairPipeline, MAX_DET, REC_COLS
+    from dodt_amd import _lib, config, device, ops, sharding, synth
+    from dodt_amd.pipeline import (CORR_CH, CORR_MAX_DISP, CORR_PAD, CORR_STRIDE2, MAX_DET, REC_COLS,
+                                   ROI, FramePairPipeline)
     cfg = config.PYRAMID_DODT if args.config == 'dodt' else config.CARS_EXAMPLE
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = device.Context(local_rank, stream=stream)
-    pps = args.pairs_per_step
+    try:
+        ctx = device.Context(local_rank)
+    except _lib.DodtError as e:
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path (%s)' % e)
+    comm = sharding.Communicator(ctx, rank, world) if (world > 1 or args.comm) else None
     computed = args.heads == 'computed'
     made = []   # pipelines built so far: later ones reuse the first one's streams
 
     def measure(conv_dtype, steps, warmup, head_dtype='f32', cfg=cfg, proposals=args.proposals,
-                from_host=False):
-        """`steps` timed steps of the pipeline built for conv_dtype, then the conv stacks
-        alone (roofline).  Returns a dict of raw measurements."""
+                from_host=False, pps=args.pairs_per_step, detail=False):
+        """`steps` timed steps of the pipeline built for conv_dtype; with detail, then the conv
+        stacks alone layer by layer (roofline) and the HBM-bound kernels alone."""
         fps = cfg['frames_per_sample']
         feat_c = 256 if cfg['extractor'] == 'vgg' else 32
         pipe = FramePairPipeline(ctx, cfg, **synth.pipeline_weights(cfg),
@@ -202,18 +236,14 @@ def main():
                                  pairs_per_step=pps,
                                  head_params=synth.head_params(feat=feat_c) if computed else None,
                                  conv_dtype=conv_dtype, head_dtype=head_dtype,
-                                 reuse_streams_of=made[0] if made and made[0].fps == fps else None)
+                                 reuse_streams_of=made[0] if made and min(made[0].nf, 2) == min(fps * pps, 2) else None)
         made.append(pipe)
-
-        # detection records live in torch memory so that RCCL can ship them
-        # (two of each: the pipeline alternates them by step parity)
-        rec = [torch.zeros((pps, fps, MAX_DET, REC_COLS), dtype=torch.float32, device='cuda')
-               for _ in range(2)]
-        cnt = [torch.zeros((pps, fps), dtype=torch.int32, device='cuda') for _ in range(2)]
-        pipe.use_record_buffers([t.data_ptr() for t in rec], [t.data_ptr() for t in cnt])
-        gathered = torch.zeros((world * pps, fps, MAX_DET, REC_COLS), dtype=torch.float32,
-                               device='cuda')
-        gathered_cnt = torch.zeros((world * pps, fps), dtype=torch.int32, device='cuda')
+        # what the exchange step fills: every rank's records of a step, by step parity
+        gathered = [ctx.zeros((world * pps, fps, MAX_DET, REC_COLS), np.float32) for _ in range(2)]
+        gathered_cnt = [ctx.zeros((world * pps, fps), np.int32) for _ in range(2)]
+        if comm is not None:
+            # the tail that refills a record buffer first joins the gather that last read it
+            pipe.on_records_reuse = lambda par, sides: [comm.join(par, s) for s in sides]
 
         # a small ring of distinct synthetic batches, resident in HBM before timing starts;
         # every pair of a batch comes from a different sequence (they are independent)
@@ -244,19 +274,13 @@ def main():
 
         state = {'n': 0, 'par': 0}
 
-        fake = os.environ.get('DODT_BENCH_FAKE_GATHER') == '1'   # rehearsal of the N > 1 stream
-        side = torch.cuda.Stream() if fake else None               # pattern on one GPU
-
         def gather(par):
-            if world > 1:
-                sharding.all_gather_records(dist, rec[par], cnt[par], gathered, gathered_cnt)
-            elif fake:     # like ProcessGroupNCCL: own stream, joined with the current one
-                cur_s = torch.cuda.current_stream()
-                side.wait_stream(cur_s)
-                with torch.cuda.stream(side):
-                    gathered[:pps].copy_(rec[par])
-                    gathered_cnt[:pps].copy_(cnt[par])
-                cur_s.wait_stream(side)
+            # on the communicator's side stream, behind what the main stream holds so far (the
+            # records of that step are complete there: FramePairPipeline.run); nothing waits for
+            # it until that record buffer is written again two steps later
+            if comm is not None:
+                comm.all_gather_records(ctx, par, pipe.rec2[par], pipe.cnt2[par], gathered[par],
+                                        gathered_cnt[par])
 
         def step(i):
             p = batches[i % n_batches]
@@ -264,7 +288,7 @@ def main():
                 par = pipe.run_from_host(p['h_pts'], p['n'], p['h_imgs'], p['heads'])
             else:
                 par = pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
-            if state['n'] > 0:     # records of the previous step are complete on this stream
+            if state['n'] > 0:     # records of the previous step are complete on the main stream
                 gather(1 - par)
             state['n'] += 1
             state['par'] = par
@@ -276,9 +300,9 @@ def main():
             state['n'] = 0
 
         def barrier():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
+            ctx.sync()                  # finish() joined every stream of the pipeline into this one
+            if comm is not None:
+                comm.barrier()          # drains the side stream, then all ranks meet
 
         # steps are pipelined two deep inside pipe.run(); finish() drains the last one, so
         # exactly `steps` complete steps (convs AND tails) lie inside the timed region
@@ -286,82 +310,140 @@ def main():
             step(i)
         drain()
         barrier()
-        # one HIP event per step on the main stream (torch's current stream = ctx's stream):
-        # event i fires when step i's convs and step i-1's tail are done, so the deltas show
-        # a slow fill / drain step or a clock ramp that the single wall-clock window hides
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 2)]
+        # one HIP event per step on the main stream: event i fires when step i's convs and step
+        # i-1's tail are done, so the deltas show a slow fill / drain step or a clock ramp that
+        # the single wall-clock window hides
+        n_ev = min(steps, 250)
         host_ms = []
         t0 = time.perf_counter()
-        evs[0].record()
+        ctx.mark(0)
         for i in range(steps):
             th = time.perf_counter()
             step(i)
-            evs[i + 1].record()
+            if i < n_ev:
+                ctx.mark(i + 1)
             host_ms.append((time.perf_counter() - th) * 1e3)
         host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3   # host side of a step
         drain()
-        evs[steps + 1].record()
+        ctx.mark(n_ev + 1)
         barrier()
         elapsed = time.perf_counter() - t0
-        step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps + 1)]
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        step_ms = [ctx.elapsed_ms(i, ctx, i + 1) for i in range(n_ev + 1)]
+        if comm is not None:
+            elapsed = comm.max_over_ranks(elapsed)
+        res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, step_ms=step_ms, host_ms=host_ms,
+                   flops=pipe.flops_per_step(), mfma_flops=pipe.mfma_flops_per_step(),
+                   head_gflop=pipe.head_flops_per_step() / 1e9, conv_bytes=pipe.conv_bytes_per_step(),
+                   anchors=list(pipe.last_anchor_counts), steps=steps, pps=pps)
+        if comm is not None and rank == 0:
+            # the exchange really happened: rank 0's own block of the last gather equals its records
+            par = state['par']
+            g = gathered[par].download()[rank * pps:(rank + 1) * pps]
+            res['gather_ok'] = bool(np.array_equal(g, pipe.rec2[par].download()))
 
-        # ---- roofline of the dominant kernel family: the conv stacks -----------------------
-        # measured live with HIP events on the stream the kernels run on
-        # (each net alone on its own stream, so the kernel durations do not overlap)
+        # ---- the conv stacks alone (each net by itself on its own stream, so that kernel
+        #      durations do not overlap), layer by layer: HIP events on the stream the kernels run on
         reps = max(3, min(steps, 10))
-        barrier()
+        nets = ((pipe.bev_net, ctx, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck']),
+                (pipe.img_net, pipe.img_ctx, pipe.feat[0]['img_feat'], pipe.feat[0]['img_bneck']))
         conv_ms = 0.0
-        for net, c, f, b in ((pipe.bev_net, ctx, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck']),
-                             (pipe.img_net, pipe.img_ctx, pipe.feat[0]['img_feat'],
-                              pipe.feat[0]['img_bneck'])):
+        for net, c, f, b in nets:
             c.sync()
             c.timer_start()
             for _ in range(reps):
                 net.forward_device(None, f, b)
             conv_ms += c.timer_stop() / reps
-        # both nets side by side, as in the timed steps (but nothing else on the GPU)
-        ctx.sync()
-        pipe.img_ctx.sync()
-        ctx.timer_start()
-        for _ in range(reps):
-            pipe.img_ctx.wait_for(ctx)
-            pipe.bev_net.forward_device(None, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck'])
-            pipe.img_net.forward_device(None, pipe.feat[0]['img_feat'], pipe.feat[0]['img_bneck'])
-            ctx.wait_for(pipe.img_ctx)
-        both_ms = ctx.timer_stop() / reps
-        res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, conv_ms=conv_ms, reps=reps,
-                   step_ms=step_ms, host_ms=host_ms,
-                   both_ms=both_ms,
-                   flops=pipe.flops_per_step(), mfma_flops=pipe.mfma_flops_per_step(),
-                   head_gflop=pipe.head_flops_per_step() / 1e9,
-                   conv_bytes=pipe.conv_bytes_per_step(),
-                   anchors=list(pipe.last_anchor_counts), steps=steps)
+        res.update(conv_ms=conv_ms, reps=reps)
+        if detail:
+            layers = []
+            for net, c, f, b in nets:
+                acc = None
+                for _ in range(reps):
+                    cur = net.forward_timed(None, f, b)
+                    if acc is None:
+                        acc = cur
+                    else:
+                        for a_, c_ in zip(acc, cur):
+                            a_['ms'] += c_['ms']
+                for a_ in acc:
+                    a_['ms'] /= reps
+                layers += acc
+            res['layers'] = layers
+            # both nets side by side, as in the timed steps (but nothing else on the GPU)
+            ctx.sync()
+            pipe.img_ctx.sync()
+            ctx.timer_start()
+            for _ in range(reps):
+                pipe.img_ctx.wait_for(ctx)
+                pipe.bev_net.forward_device(None, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck'])
+                pipe.img_net.forward_device(None, pipe.feat[0]['img_feat'], pipe.feat[0]['img_bneck'])
+                ctx.wait_for(pipe.img_ctx)
+            res['both_ms'] = ctx.timer_stop() / reps
+            # ---- the HBM-bound kernels alone, on the inputs the last step left behind -----------
+            if fps == 2 and computed and cfg['extractor'] != 'vgg':
+                hreps = 20
+                fr, feat = pipe.fr, pipe.feat[state['par']]
+                n_pts = batches[0]['n'][0]
+
+                def timed(fn):
+                    fn()
+                    ctx.sync()
+                    ctx.timer_start()
+                    for _ in range(hreps):
+                        fn()
+                    return ctx.timer_stop() / hreps * 1e3      # us
+                bev_hw, FC = (pipe.bev_fh, pipe.bev_fw), pipe.feat_c
+                feat_b0 = feat['bev_feat'].offset(0, bev_hw + (FC,))
+                feat_b1 = feat['bev_feat'].offset(4 * pipe.bev_fh * pipe.bev_fw * FC, bev_hw + (FC,))
+                d_bev = ctx.empty((pipe.bev_h, pipe.bev_w, cfg['bev_depth']), np.float32)
+                n_top = int(fr[0]['top_count'].download()[0])
+                out_b = n_top * ROI * ROI * FC * 4
+                hbm = []
+                us = timed(lambda: ops.bev_slices(ctx, batches[0]['pts'][0], n_pts, pipe.bp, d_bev, fr[0]['occ']))
+                hbm.append(dict(kernel='hipMemsetAsync + vox_scatter + vox_finalize',
+                                stage='a0-a3 voxeliser, %d points -> (700,800,6) maps' % n_pts,
+                                algorithmic_bytes=16 * n_pts + pipe.bev_h * pipe.bev_w * cfg['bev_depth'] * 4,
+                                us=us))
+                us = timed(lambda: ops.crop_and_resize(ctx, feat_b0, bev_hw + (FC,), fr[0]['top_bev'], pipe.P,
+                                                       fr[0]['top_count'], (ROI, ROI), fr[0]['bev_rois']))
+                hbm.append(dict(kernel='crop_kernel<4>', stage='a11 stage-2 ROI crop, %d proposals x 7x7x%d, BEV map'
+                                % (n_top, FC),
+                                algorithmic_bytes=16 * n_top + min(4 * out_b, pipe.bev_fh * pipe.bev_fw * FC * 4) + out_b,
+                                us=us))
+                corr_map = pipe.head_scratch[0]['corr_map']
+                us = timed(lambda: ops.correlation(ctx, feat_b0, feat_b1, bev_hw + (FC,), CORR_MAX_DISP,
+                                                   CORR_STRIDE2, CORR_PAD, corr_map))
+                hbm.append(dict(kernel='correlation_kernel', stage='f1 correlation of the pair\'s BEV features',
+                                algorithmic_bytes=(2 * FC + CORR_CH) * pipe.bev_fh * pipe.bev_fw * 4, us=us))
+                for h in hbm:
+                    h['us'] = round(h['us'], 2)
+                    h['gbps'] = round(h['algorithmic_bytes'] / h['us'] / 1e3, 1)
+                    h['frac_of_hbm_peak'] = round(h['gbps'] / HBM_PEAK, 4)
+                res['hbm'] = hbm
         pipe.close()
         return res
 
     import gc
     if os.environ.get('DODT_BENCH_GC', 'freeze') == 'freeze':
-        # everything allocated so far (torch, numpy, the package) leaves the collector's
-        # generations: a full collection of that heap in the middle of a 0.1 s timed window
-        # would stall the enqueueing thread for tens of ms
+        # everything allocated so far (numpy, the package) leaves the collector's generations: a
+        # full collection of that heap in the middle of a 0.1 s timed window would stall the
+        # enqueueing thread for tens of ms
         gc.collect()
         gc.freeze()
-    m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype)
+    pps = args.pairs_per_step
+    m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype, detail=True)
     elapsed, host_enqueue_ms, conv_ms, reps = m['elapsed'], m['host_enqueue_ms'], m['conv_ms'], m['reps']
     alt = None
     if not args.no_alt:
-        # the other conv arithmetic, same workload, a shorter run: reported beside the main
-        # measurement, never part of `value`
+        # other arithmetics / batchings of the same workload, shorter runs: reported beside the
+        # main measurement, never part of `value`
         k = max(5, args.steps // 2)
 
         def short(conv_dtype, head_dtype, **kw):
             a = measure(conv_dtype, k, 2, head_dtype, **kw)
             return {'conv_dtype': conv_dtype, 'head_dtype': head_dtype,
-                    'value': round(world * k * pps / a['elapsed'], 3), 'unit': 'frame-pairs/s',
+                    'pairs_per_step': a['pps'],
+                    'value': round(world * k * a['pps'] / a['elapsed'], 3), 'unit': 'frame-pairs/s',
                     'steps': k, 'ms_per_step': round(a['elapsed'] / k * 1e3, 4),
                     'conv_stacks_tflops': round(a['flops'] / (a['conv_ms'] * 1e-3) / 1e12, 2),
                     'conv_stacks_ms': round(a['conv_ms'], 4)}
@@ -369,11 +451,14 @@ def main():
                        'fp32 accumulate -- passes the fp32 layer tests at 1e-4 '
                        '(tests/test_gpu_conv_split.py); bf16 conv = BASELINE.json configs[2]\'s '
                        'bf16 conv path (bars in tests/test_gpu_conv_bf16.py); bf16 heads = the '
-                       "same for the FC layers; f32 = the reference's arithmetic on the fp32 MFMA",
+                       "same for the FC layers; f32 = the reference's arithmetic on the fp32 MFMA; "
+                       'pairs_per_step > 1 = that many independent frame pairs batched through every launch',
                'runs': [short(c, h) for c, h in (('f32', 'f32'), ('f32s', 'f32'), ('bf16', 'f32'),
                                                   ('bf16', 'bf16'))
                         if (c, h) != (args.conv_dtype, args.head_dtype) and (computed or h == 'f32')]}
         if args.config == 'dodt':
+            alt['batched'] = [short(c, h, pps=n) for c, h in (('f32', 'f32'), ('bf16', 'bf16'))
+                              for n in (2, 4) if computed and n != pps]
             # BASELINE.json configs[0]: single frames through the AVOD cars_example
             # configuration (plain VGG extractors, 480 x 1590 image, 300 proposals, fp32)
             r = short('f32', 'f32', cfg=config.CARS_EXAMPLE,
@@ -388,58 +473,64 @@ def main():
                            'pinned host memory inside each step'
                            % (args.points, 2 * (args.points * 16 + 1242 * 375 * 3) / 1e6))
             alt['pcie_inclusive'] = r
-    flops = m['flops']
-    achieved = flops / (conv_ms * 1e-3) / 1e12
-    # HBM bytes per conv launch: PMC counters cannot be read from inside this process; the
-    # figure comes from the rocprofv3 --pmc passes over this same command (profiles/)
-    traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, 'profiles', {'f32': 'r2_conv_traffic.json',
-                                         'f32s': 'r2f32s_conv_traffic.json',
-                                         'bf16': 'r2bf16_conv_traffic.json'}[args.conv_dtype])
-    if os.path.exists(tj):
-        t = json.load(open(tj))
-        traffic = round(t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'])
-        traffic_src = t['source']
-    common = dict(traffic=traffic, traffic_unit='bytes/launch', traffic_source=traffic_src,
-                  kernel='wino43_f32_kernel (24 launches per step) + deconv3x3_f32_kernel (6 transposed convs) '
-                         '+ 2 first-layer launches',
-                  launch_ms=round(conv_ms, 4), algorithmic_gflop=round(flops / 1e9, 2),
-                  algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
-                  launches_per_step=32, avg_launch_us=round(conv_ms * 1e3 / 32, 2),
-                  side_by_side_ms=round(m['both_ms'], 4),
-                  side_by_side_tflops=round(flops / (m['both_ms'] * 1e-3) / 1e12, 2),
-                  measured='HIP events, each net alone on its stream, %d reps after the '
-                           'timed region' % reps)
-    if args.conv_dtype == 'f32':
-        # fp32 MFMA: 157.3 TFLOP/s dense (MI355X_MICROARCH.md chip table); every layer is
-        # MFMA-bound at fp32.  `achieved` prices the ALGORITHMIC FLOPs (2 M N K of the direct
-        # form); the 3x3 stride-1 layers run as Winograd F(4x4,3x3), which executes
-        # 36/144 of them (so `frac` can exceed 1: the direct form's roof is not this algorithm's):
-        # what the matrix pipe really does is given beside it.
-        executed = m['mfma_flops'] / (conv_ms * 1e-3) / 1e12
-        roofline = dict(bound='mfma', achieved=round(achieved, 2), peak=157.3, unit='TFLOP/s',
-                        frac=round(achieved / 157.3, 4),
-                        executed_gflop=round(m['mfma_flops'] / 1e9, 2),
-                        executed_tflops=round(executed, 2),
-                        executed_frac=round(executed / 157.3, 4),
-                        algorithm='Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 for the 3x3 '
-                                  'stride-1 layers (fp32 throughout; 4x fewer multiplications than '
-                                  'the direct form priced by `achieved`), an LDS-DMA staged direct kernel for the transposed '
-                                  'convs, direct implicit GEMM for the first layers', **common)
-    elif args.conv_dtype == 'f32s':
-        # split mode: three bf16 MFMAs per product term -> 3x the algorithmic FLOPs on the
-        # bf16 pipe (2.5 PFLOP/s dense); the fp32-equivalent rate is given beside it
-        roofline = dict(bound='mfma', achieved=round(3 * achieved, 2), peak=2500.0, unit='TFLOP/s',
-                        frac=round(3 * achieved / 2500.0, 4), executed_flops='3 x algorithmic',
-                        fp32_equivalent_tflops=round(achieved, 2), **common)
-    else:
-        # bf16 MFMA (2.5 PFLOP/s) makes the stacks 16x cheaper in matrix time than in fp32:
-        # they are bound by moving the maps (HBM ~8 TB/s), which is what is priced here;
-        # the matrix-pipe fraction is given beside it
-        gbs = m['conv_bytes'] / (conv_ms * 1e-3) / 1e9
-        roofline = dict(bound='hbm', achieved=round(gbs, 1), peak=8000.0, unit='GB/s',
-                        frac=round(gbs / 8000.0, 4), mfma_tflops=round(achieved, 2),
-                        mfma_frac_of_2500=round(achieved / 2500.0, 4), **common)
+
+    # ---- roofline of the dominant kernel ---------------------------------------------------------
+    # Everything below is measured in this run with HIP events on the streams the kernels run on;
+    # only the PMC byte counts come from the rocprofv3 --pmc passes over this same command
+    # (profiles/), because counters cannot be read from inside the process.
+    by_kernel = _group_by_kernel(m['layers'])
+    dom = max(by_kernel.values(), key=lambda k_: k_['ms'])
+    n_launch = sum(k_['launches'] for k_ in by_kernel.values())
+    layers_ms = sum(k_['ms'] for k_ in by_kernel.values())
+    peak = FP32_MFMA_PEAK if args.conv_dtype == 'f32' else BF16_MFMA_PEAK
+    tj = _profile_json({'f32': 'r3_conv_traffic.json', 'f32s': 'r3f32s_conv_traffic.json',
+                        'bf16': 'r3bf16_conv_traffic.json'}[args.conv_dtype])
+    traffic = tj['kernels'].get(dom['kernel']) if tj else None
+    kernels = []
+    for k_ in sorted(by_kernel.values(), key=lambda k_: -k_['ms']):
+        tf = k_['flops_executed'] / (k_['ms'] * 1e-3) / 1e12
+        kernels.append(dict(kernel=k_['kernel'], launches_per_step=k_['launches'], ms_per_step=round(k_['ms'], 4),
+                            avg_launch_us=round(k_['ms'] * 1e3 / k_['launches'], 2),
+                            executed_gflop=round(k_['flops_executed'] / 1e9, 2), executed_tflops=round(tf, 2),
+                            frac=round(tf / peak, 4),
+                            direct_equivalent_tflops=round(k_['flops_direct'] / (k_['ms'] * 1e-3) / 1e12, 2),
+                            algorithmic_gbps=round(k_['bytes'] / (k_['ms'] * 1e-3) / 1e9, 1),
+                            layers=k_['layers']))
+    d = kernels[0]
+    all_tf = m['mfma_flops'] / (layers_ms * 1e-3) / 1e12
+    roofline = dict(
+        bound='mfma', kernel=d['kernel'], launches_per_step=d['launches_per_step'],
+        avg_launch_us=d['avg_launch_us'],
+        # executed MFMA FLOPs of the dominant kernel's launches / their stand-alone duration
+        achieved=d['executed_tflops'], peak=peak, unit='TFLOP/s', frac=d['frac'],
+        algorithmic_gflop_per_launch=round(d['executed_gflop'] / d['launches_per_step'], 3),
+        direct_equivalent_tflops=d['direct_equivalent_tflops'],
+        traffic=(round(traffic['fetch_bytes_per_launch'] + traffic['write_bytes_per_launch'])
+                 if traffic else None),
+        traffic_unit='bytes/launch', traffic_source=tj['source'] if tj else None,
+        algorithmic_bytes_per_launch=round(by_kernel[d['kernel']]['bytes'] / d['launches_per_step']),
+        arithmetic={'f32': 'fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2), peak 157.3 TFLOP/s dense',
+                    'f32s': 'three bf16 MFMAs per product term (split mode), fp32 accumulate',
+                    'bf16': 'bf16 MFMA, fp32 accumulate'}[args.conv_dtype],
+        measured='HIP event pair around every layer, each net alone on its stream, %d forwards after the '
+                 'timed region; frac = executed MFMA FLOPs / time / peak' % reps,
+        conv_stacks=dict(launches_per_step=n_launch, ms=round(conv_ms, 4), layers_ms=round(layers_ms, 4),
+                         executed_gflop=round(m['mfma_flops'] / 1e9, 2), executed_tflops=round(all_tf, 2),
+                         frac=round(all_tf / peak, 4),
+                         direct_gflop=round(m['flops'] / 1e9, 2),
+                         direct_equivalent_tflops=round(m['flops'] / (conv_ms * 1e-3) / 1e12, 2),
+                         algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
+                         side_by_side_ms=round(m['both_ms'], 4),
+                         side_by_side_direct_equivalent_tflops=round(m['flops'] / (m['both_ms'] * 1e-3) / 1e12, 2)),
+        kernels=kernels)
+    hbm = m.get('hbm')
+    if hbm:
+        hj = _profile_json('r3_hbm_traffic.json')
+        for h in hbm:
+            t = hj['kernels'].get(h['kernel']) if hj else None
+            h['traffic'] = round(t['fetch_bytes'] + t['write_bytes']) if t else None
+            h['traffic_source'] = hj['source'] if (hj and t) else None
+        roofline['hbm'] = hbm
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -472,6 +563,10 @@ def main():
                         % (args.points // 1000, args.proposals)),
                        'head_gflop_per_step': round(m['head_gflop'], 2),
                        'pairs_per_step_per_gpu': pps, 'parallelism': 'pair-shard x%d' % world,
+                       'exchange': ('RCCL all-gather of (pairs,2,100,17) f32 + counts per step, side stream, '
+                                    'C-ABI (no PyTorch)%s' % ('; rank 0 block verified' if m.get('gather_ok') else '')
+                                    ) if comm is not None else 'none (one rank)',
+                       'conv_mode': os.environ.get('DODT_CONV_WINO', 'default'),
                        'anchors_kept': m['anchors']},
             'roofline': roofline,
         }
@@ -480,8 +575,10 @@ def main():
         if baseline is not None:
             out['cpu_baseline'] = baseline
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == '__main__':

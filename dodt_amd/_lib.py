@@ -49,6 +49,12 @@ class BevParams(C.Structure):
     ]
 
 
+class LayerInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 32), ('kernel', C.c_char * 48), ('launches', C.c_int32),
+                ('items', C.c_int32), ('flops_direct', C.c_double), ('flops_executed', C.c_double),
+                ('bytes', C.c_double), ('ms', C.c_float), ('reserved_', C.c_int32)]
+
+
 _vp = C.c_void_p
 _i = C.c_int
 _f = C.c_float
@@ -91,6 +97,7 @@ SIGNATURES = {
                                       C.POINTER(_f), _f, _f, _pf, _pf, _pf]),
     'dodt_img_preprocess': (_i, [_vp, _vp, _i, _i, _i, _i, _i,
                                  C.POINTER(_f), _pf]),
+    'dodt_conv_mode': (_i, []),
     'dodt_extractor_create': (_i, [_vp, _i, _i, _i, _i, _i, _i,
                                    C.POINTER(_vp)]),
     'dodt_extractor_destroy': (_i, [_vp]),
@@ -105,6 +112,8 @@ SIGNATURES = {
     'dodt_extractor_flops': (_d, [_vp]),
     'dodt_extractor_mfma_flops': (_d, [_vp]),
     'dodt_extractor_bytes': (_d, [_vp]),
+    'dodt_extractor_layer_count': (_i, [_vp]),
+    'dodt_extractor_forward_timed': (_i, [_vp, _pf, _pf, _pf, C.POINTER(LayerInfo), _i]),
     'dodt_crop_and_resize': (_i, [_vp, _pf, _i, _i, _i, _pf, _i, _pi32, _i, _i,
                                   _pf]),
     'dodt_correlation': (_i, [_vp, _pf, _pf, _i, _i, _i, _i, _i, _i, _pf]),

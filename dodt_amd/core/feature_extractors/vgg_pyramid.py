@@ -88,6 +88,21 @@ class _VggPyr(object):
             None if d_bottleneck is None else C.c_void_p(d_bottleneck.ptr)),
             'dodt_extractor_forward')
 
+    def forward_timed(self, d_in, d_feat, d_bottleneck=None):
+        """One forward with a HIP event pair around every layer; waits for the stream.  Returns a
+        list of dicts in launch order: name, kernel (the __global__ function), launches, items,
+        flops_direct, flops_executed, bytes, ms."""
+        lib = self._ctx.lib
+        n = lib.dodt_extractor_layer_count(self._handle)
+        info = (_lib.LayerInfo * n)()
+        _lib.check(lib.dodt_extractor_forward_timed(
+            self._handle, None if d_in is None else C.c_void_p(d_in.ptr), C.c_void_p(d_feat.ptr),
+            None if d_bottleneck is None else C.c_void_p(d_bottleneck.ptr), info, n),
+            'dodt_extractor_forward_timed')
+        return [dict(name=i.name.decode(), kernel=i.kernel.decode(), launches=i.launches,
+                     items=i.items, flops_direct=i.flops_direct, flops_executed=i.flops_executed,
+                     bytes=i.bytes, ms=i.ms) for i in info]
+
     def input_view(self):
         """DeviceArray aliasing the extractor's own input buffer (zero copy)."""
         p = C.c_void_p()

@@ -62,6 +62,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 }  // namespace dodt
 
+constexpr int kMarkSlots = 256;  // dodt_mark slots per context
 constexpr int kFetchSlots = 32;   // dodt_fetch_i32_* slots per context
 
 struct dodt_ctx {
@@ -75,6 +76,6 @@ struct dodt_ctx {
     int num_cus = 256;
     int32_t* pinned = nullptr;       // kFetchSlots x 16 int32, hipHostMalloc
     hipEvent_t fetch_ev[kFetchSlots] = {};
-    hipEvent_t mark_ev[16] = {};     // timing marks for tools/ (created on first use)
+    hipEvent_t mark_ev[kMarkSlots] = {};     // timing marks for tools/ (created on first use)
     hipEvent_t join_ev = nullptr;    // recorded on this stream for dodt_ctx_wait_for
 };

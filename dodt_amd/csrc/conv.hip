@@ -78,6 +78,20 @@ const std::vector<KernelVariant>& variants() {
     return all;
 }
 
+}  // namespace
+
+// which form the fp32 3x3 stride-1 layers take in this process (read once)
+extern "C" int dodt_conv_mode(void) {
+    static const int mode = [] {
+        const char* e = getenv("DODT_CONV_WINO");
+        const int m = e ? atoi(e) : DODT_CONV_MODE_DEFAULT;
+        return (m == 0 || m == 1 || m == 2 || m == 4) ? m : DODT_CONV_MODE_DEFAULT;
+    }();
+    return mode;
+}
+
+namespace {
+
 // smallest padded pixel count wins; ties go to the larger output tile
 int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int parts, int batch,
                  int num_cus) {
@@ -90,7 +104,7 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     // direct form; both stacks 2.7 ms), 2 = F(2x2,3x3) with 128 accumulators, two workgroups per CU
     // (wino_kernels.h: 3.0 ms), 1 = its 256-accumulator variants, one workgroup per CU (no faster
     // than direct), 0 = the direct kernels (4.8 ms).
-    static const int wino_mode = getenv("DODT_CONV_WINO") ? atoi(getenv("DODT_CONV_WINO")) : 4;
+    static const int wino_mode = dodt_conv_mode();
     if (wino_mode > 0 && !deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].wino || Cout % vs[i].BN != 0) continue;
@@ -317,6 +331,7 @@ struct Layer {
     float *d_scale = nullptr, *d_shift = nullptr;
     bool loaded = false;
     int real_cin = 0;  // channels that carry data (conv1_1 of the image net: 3 of 4)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // dodt_extractor_forward_timed
 };
 
 enum Buf { X0, C1A, CAT1, P1, C2A, CAT2, P2, C3A, C3B, CAT3, P3, C4A, C4B, C4C, F3, F2, F1, NBUF };
@@ -339,6 +354,7 @@ struct dodt_extractor {
     float bneck_scale = 1.0f, bneck_shift = 0.0f;
     bool bneck_loaded = false;
     double flops = 0.0;
+    bool timed = false;   // this forward records an event pair around every layer
 };
 
 namespace {
@@ -473,10 +489,51 @@ bool layer_can_pool(const Layer& l) {
 // pool_dst >= 0: the layer also writes its 2x2 max pool into that buffer
 int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h,
               float* bneck_out = nullptr, int pool_dst = -1) {
+    if (ex->timed) DODT_HIP_CHECK(hipEventRecord(l.ev0, ex->ctx->stream));
     int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h, bneck_out, pool_dst);
     if (rc == DODT_OK && l.tail.n_items > 0)
         rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h, bneck_out, pool_dst);
+    if (rc == DODT_OK && ex->timed) DODT_HIP_CHECK(hipEventRecord(l.ev1, ex->ctx->stream));
     return rc;
+}
+
+// the __global__ function a variant launches (what rocprofv3 --kernel-trace lists)
+const char* kernel_name(const KernelVariant& v) {
+    if (v.wino) return v.wino_m == 4 ? "wino43_f32_kernel" : "wino3x3_f32_kernel";
+    if (v.deconv_dma) return "deconv3x3_f32_kernel";
+    if (v.dma) return "conv3x3_bf16_dma_kernel";
+    if (v.small_cin) return "conv3x3_small_cin_kernel";
+    return "conv3x3_mfma_kernel";
+}
+
+double layer_direct_flops(const dodt_extractor* ex, const Layer& l) {
+    return 2.0 * l.H * l.W * (double)l.Cout * 9.0 * l.real_cin * ex->batch;
+}
+
+// FLOPs the matrix pipe executes for a layer: the Winograd kernels multiply 36 times per 4x4
+// outputs and channel pair (F(4x4,3x3)) or 16 times per 2x2 (F(2x2,3x3)) where the direct form
+// needs 144 / 36; split mode issues three bf16 MFMAs per product term
+double layer_executed_flops(const dodt_extractor* ex, const Layer& l) {
+    const KernelVariant& kv = variants()[l.main.variant];
+    const double direct = layer_direct_flops(ex, l);
+    if (kv.wino) return direct * (kv.wino_m == 4 ? 36.0 / 144.0 : 16.0 / 36.0);
+    return kv.parts == 2 ? 3.0 * direct : direct;
+}
+
+// algorithmic HBM bytes of a layer: input map and weights read once, output map (and its pooled
+// copy) written once; split mode keeps two bf16 maps (hi + lo) and two bf16 weight sets per tensor
+double layer_bytes(const dodt_extractor* ex, const Layer& l) {
+    const Buffer& src = ex->buf[l.src];
+    const Buffer& dst = ex->buf[l.dst];
+    const double in_e = src.bf16 ? 2.0 * src.parts : 4.0;
+    const double out_e = dst.bf16 ? 2.0 * dst.parts : 4.0;
+    const double w_e = (ex->bf16 && &l != &ex->layers[0]) ? 2.0 * ex->parts : 4.0;
+    const double oh = l.deconv ? 2.0 * l.H : l.H, ow = l.deconv ? 2.0 * l.W : l.W;
+    double b = ex->batch * ((double)l.H * l.W * l.real_cin * in_e + oh * ow * l.Cout * out_e) +
+               9.0 * l.real_cin * l.Cout * w_e;
+    if (l.name == "conv1_2" || l.name == "conv2_2" || l.name == "conv3_3")
+        b += ex->batch * std::floor(oh / 2) * std::floor(ow / 2) * l.Cout * out_e;
+    return b;
 }
 
 // Work items of a layer.  The main launch walks big tiles; when their count leaves the
@@ -711,6 +768,10 @@ int dodt_extractor_destroy(dodt_extractor* ex) {
         if (l.d_shift) (void)hipFree(l.d_shift);
     }
     if (ex->d_bneck_w) (void)hipFree(ex->d_bneck_w);
+    for (Layer& l : ex->layers) {
+        if (l.ev0) (void)hipEventDestroy(l.ev0);
+        if (l.ev1) (void)hipEventDestroy(l.ev1);
+    }
     if (ex->d_counters) (void)hipFree(ex->d_counters);
     if (ex->d_zeros) (void)hipFree(ex->d_zeros);
     delete ex;
@@ -1036,22 +1097,8 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
 
 double dodt_extractor_bytes(const dodt_extractor* ex) {
     if (!ex) return 0.0;
-    // algorithmic HBM bytes of one forward: every layer reads its input map and its weights
-    // once and writes its output map once (pooled copies and the bottleneck included); split
-    // mode keeps two bf16 maps (hi + lo) and two bf16 weight sets per tensor
     double b = 0.0;
-    for (const Layer& l : ex->layers) {
-        const Buffer& src = ex->buf[l.src];
-        const Buffer& dst = ex->buf[l.dst];
-        const double in_e = src.bf16 ? 2.0 * src.parts : 4.0;
-        const double out_e = dst.bf16 ? 2.0 * dst.parts : 4.0;
-        const double w_e = (ex->bf16 && &l != &ex->layers[0]) ? 2.0 * ex->parts : 4.0;
-        const double oh = l.deconv ? 2.0 * l.H : l.H, ow = l.deconv ? 2.0 * l.W : l.W;
-        b += ex->batch * ((double)l.H * l.W * l.real_cin * in_e + oh * ow * l.Cout * out_e) +
-             9.0 * l.real_cin * l.Cout * w_e;
-        if (l.name == "conv1_2" || l.name == "conv2_2" || l.name == "conv3_3")
-            b += ex->batch * std::floor(oh / 2) * std::floor(ow / 2) * l.Cout * out_e;
-    }
+    for (const Layer& l : ex->layers) b += layer_bytes(ex, l);
     if (ex->kind == DODT_EXTRACTOR_VGG)   // upsampling: conv4_3 read, the feature map written
         b += (double)ex->batch * ((double)ex->buf[C4C].H * ex->buf[C4C].W * 256 +
                                   (double)ex->out_h * ex->out_w * 256) * 4.0;
@@ -1061,17 +1108,40 @@ double dodt_extractor_bytes(const dodt_extractor* ex) {
 
 double dodt_extractor_mfma_flops(const dodt_extractor* ex) {
     if (!ex) return 0.0;
-    // FLOPs the matrix pipe executes: Winograd F(2x2,3x3) layers multiply 16 times per 2x2
-    // outputs and channel pair instead of 36
     double f = 0.0;
-    for (const Layer& l : ex->layers) {
-        const double direct = 2.0 * l.H * l.W * (double)l.Cout * 9.0 * l.real_cin * ex->batch;
-        {
-            const KernelVariant& kv = variants()[l.main.variant];
-            f += kv.wino ? direct * (kv.wino_m == 4 ? 36.0 / 144.0 : 16.0 / 36.0) : direct;
-        }
-    }
+    for (const Layer& l : ex->layers) f += layer_executed_flops(ex, l);
     return f;
+}
+
+int dodt_extractor_layer_count(const dodt_extractor* ex) { return ex ? (int)ex->layers.size() : 0; }
+
+int dodt_extractor_forward_timed(dodt_extractor* ex, const float* d_in, float* d_feat_out,
+                                 float* d_bottleneck_out, dodt_layer_info* info, int n_info) {
+    DODT_REQUIRE(ex && info && n_info >= (int)ex->layers.size(),
+                 "dodt_extractor_forward_timed: info must hold dodt_extractor_layer_count() entries");
+    for (Layer& l : ex->layers) {
+        if (!l.ev0) DODT_HIP_CHECK(hipEventCreate(&l.ev0));
+        if (!l.ev1) DODT_HIP_CHECK(hipEventCreate(&l.ev1));
+    }
+    ex->timed = true;
+    const int rc = dodt_extractor_forward(ex, d_in, d_feat_out, d_bottleneck_out);
+    ex->timed = false;
+    if (rc) return rc;
+    DODT_HIP_CHECK(hipStreamSynchronize(ex->ctx->stream));
+    for (size_t i = 0; i < ex->layers.size(); ++i) {
+        const Layer& l = ex->layers[i];
+        dodt_layer_info& o = info[i];
+        memset(&o, 0, sizeof(o));
+        snprintf(o.name, sizeof(o.name), "%s", l.name.c_str());
+        snprintf(o.kernel, sizeof(o.kernel), "%s", kernel_name(variants()[l.main.variant]));
+        o.launches = l.tail.n_items > 0 ? 2 : 1;
+        o.items = l.main.n_items + l.tail.n_items;
+        o.flops_direct = layer_direct_flops(ex, l);
+        o.flops_executed = layer_executed_flops(ex, l);
+        o.bytes = layer_bytes(ex, l);
+        DODT_HIP_CHECK(hipEventElapsedTime(&o.ms, l.ev0, l.ev1));
+    }
+    return DODT_OK;
 }
 
 double dodt_extractor_flops(const dodt_extractor* ex) {

@@ -105,7 +105,7 @@ int dodt_ctx_destroy(dodt_ctx* ctx) {
     for (int i = 0; i < kFetchSlots; ++i)
         if (ctx->fetch_ev[i]) (void)hipEventDestroy(ctx->fetch_ev[i]);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < kMarkSlots; ++i)
         if (ctx->mark_ev[i]) (void)hipEventDestroy(ctx->mark_ev[i]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -129,15 +129,15 @@ int dodt_ctx_wait_for(dodt_ctx* ctx, dodt_ctx* other) {
 }
 
 int dodt_mark(dodt_ctx* ctx, int slot) {
-    DODT_REQUIRE(ctx && slot >= 0 && slot < 16, "dodt_mark: bad argument");
+    DODT_REQUIRE(ctx && slot >= 0 && slot < kMarkSlots, "dodt_mark: bad argument");
     if (!ctx->mark_ev[slot]) DODT_HIP_CHECK(hipEventCreate(&ctx->mark_ev[slot]));
     DODT_HIP_CHECK(hipEventRecord(ctx->mark_ev[slot], ctx->stream));
     return DODT_OK;
 }
 
 int dodt_mark_elapsed(dodt_ctx* from, int from_slot, dodt_ctx* to, int to_slot, float* ms) {
-    DODT_REQUIRE(from && to && ms && from_slot >= 0 && from_slot < 16 && to_slot >= 0 &&
-                     to_slot < 16 && from->mark_ev[from_slot] && to->mark_ev[to_slot],
+    DODT_REQUIRE(from && to && ms && from_slot >= 0 && from_slot < kMarkSlots && to_slot >= 0 &&
+                     to_slot < kMarkSlots && from->mark_ev[from_slot] && to->mark_ev[to_slot],
                  "dodt_mark_elapsed: bad argument or mark never recorded");
     DODT_HIP_CHECK(hipEventSynchronize(to->mark_ev[to_slot]));
     DODT_HIP_CHECK(hipEventElapsedTime(ms, from->mark_ev[from_slot], to->mark_ev[to_slot]));

@@ -182,6 +182,10 @@ class FramePairPipeline(object):
         self.cnt2 = [ctx.zeros((self.pairs, self.fps), i32) for _ in range(2)]
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]   # last finished step
         self.last_anchor_counts = [0] * self.nf
+        # hook(parity, side contexts), called before a tail refills the record buffers of that
+        # parity: the exchange step (sharding.Communicator.join) makes the tails wait for the
+        # all-gather that last read them, two steps earlier
+        self.on_records_reuse = None
         self.mark_steps = ()           # tools/pipe_marks.py: steps whose stages get timing marks
         self.marks = {}                # name -> (context, slot)
         ctx.sync()
@@ -218,8 +222,8 @@ class FramePairPipeline(object):
         return [arr.offset(n * f, shape) for f in range(self.nf)]
 
     def use_record_buffers(self, rec_ptrs, cnt_ptrs):
-        """Write detection records into caller-owned device memory (e.g. the torch tensors
-        handed to torch.distributed.all_gather): two of each, used by step parity."""
+        """Write detection records into caller-owned device memory (e.g. buffers registered with
+        a communication library): two of each, used by step parity."""
         self.rec2 = [self.ctx.wrap(p, (self.pairs, self.fps, MAX_DET, REC_COLS), np.float32)
                      for p in rec_ptrs]
         self.cnt2 = [self.ctx.wrap(p, (self.pairs, self.fps), np.int32) for p in cnt_ptrs]
@@ -352,6 +356,8 @@ class FramePairPipeline(object):
         plane = cfg['ground_plane']
         if os.environ.get('DODT_PIPE_NO_TAIL'):      # (tools/: the step without its tail)
             return
+        if self.on_records_reuse is not None:
+            self.on_records_reuse(cur, self.sides)
         for f in range(nf):
             c, b, A = self.sides[f % ns], fr[f], counts[f]
             computed = heads is None

@@ -52,7 +52,7 @@ int dodt_ctx_create_high_priority(int device_id, dodt_ctx** out);
 int dodt_ctx_create_on_stream(int device_id, void* hip_stream, dodt_ctx** out);
 int dodt_ctx_destroy(dodt_ctx* ctx);
 int dodt_ctx_sync(dodt_ctx* ctx);
-/* Timing marks (16 per context) for stream-level timelines: record one on ctx's stream;
+/* Timing marks (256 per context) for stream-level timelines: record one on ctx's stream;
  * elapsed GPU time between two marks, possibly of different contexts (waits for `to`). */
 int dodt_mark(dodt_ctx* ctx, int slot);
 int dodt_mark_elapsed(dodt_ctx* from, int from_slot, dodt_ctx* to, int to_slot, float* ms);
@@ -214,6 +214,13 @@ typedef struct dodt_extractor dodt_extractor;
  * error ~2^-16 per product instead of bf16's 2^-8, within the 1e-4 bar of the fp32 tests
  * (tests/test_gpu_conv_split.py runs them at the fp32 tolerances). */
 #define DODT_EXTRACTOR_SPLIT 0x400
+/* Form of the fp32 3x3 stride-1 layers (everything else has one kernel): 4 = Winograd F(4x4,3x3),
+ * 2 = Winograd F(2x2,3x3), 1 = its one-workgroup-per-CU variants, 0 = direct implicit GEMM.  All are
+ * fp32 throughout and within the 1e-4 layer bar; they differ in speed and in how far the rounding
+ * noise of a whole stack lies from the exact sums (DESIGN.md 2 / 5.0 give both, and the rule that
+ * chose the default).  DODT_CONV_WINO in the environment overrides the default, once per process. */
+#define DODT_CONV_MODE_DEFAULT 4
+int dodt_conv_mode(void);
 /* in_c: channels of the input tensor as stored (6 for BEV; 4 for the padded
  * image); pad_top: zero rows added on top (4 for BEV 700->704, 0 for images);
  * batch: frames processed per forward call (2 = both frames of a pair). */
@@ -248,12 +255,33 @@ int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* 
 /* FLOPs of one forward call (2*M*N*K summed over conv layers, all frames): the ALGORITHMIC
  * count of the direct form, whatever kernel computes a layer. */
 double dodt_extractor_flops(const dodt_extractor* ex);
-/* FLOPs the matrix pipe executes for one forward: the fp32 3x3 stride-1 layers run as Winograd
- * F(2x2,3x3) (16 multiplications per 2x2 outputs where the direct form needs 36; fp32 throughout,
- * within 1e-6 of the direct result) unless DODT_CONV_WINO=0 is set in the environment. */
+/* FLOPs the matrix pipe executes for one forward.  The fp32 3x3 stride-1 layers run as Winograd
+ * minimal filtering, fp32 throughout: F(4x4,3x3) (36 multiplications per 4x4 outputs and channel pair
+ * where the direct form needs 144) or F(2x2,3x3) (16 per 2x2 outputs instead of 36), selected by
+ * DODT_CONV_WINO=4|2 in the environment (0: the direct kernels; DESIGN.md 5.0 states the default and
+ * each form's distance to the direct result); split mode issues three bf16 MFMAs per product. */
 double dodt_extractor_mfma_flops(const dodt_extractor* ex);
 /* Algorithmic HBM bytes of one forward (each map and the weights read / written once). */
 double dodt_extractor_bytes(const dodt_extractor* ex);
+/* What a forward is made of, layer by layer in launch order, and how long each layer's launches
+ * took in one forward (a HIP event pair around every layer on the extractor's stream; the call
+ * waits for the stream).  bench.py's roofline object is built from this: `kernel` is the
+ * __global__ function a rocprofv3 kernel trace lists, flops_executed what the matrix pipe issues
+ * for the layer (see dodt_extractor_mfma_flops), bytes the layer's share of dodt_extractor_bytes. */
+typedef struct dodt_layer_info {
+    char name[32];          /* TF variable scope of the layer */
+    char kernel[48];
+    int32_t launches;       /* 1, or 2 when a tail launch evens out the last round */
+    int32_t items;          /* work items (tiles x channel tiles x frames) */
+    double flops_direct;    /* 2 M N K of the direct form */
+    double flops_executed;
+    double bytes;
+    float ms;
+    int32_t reserved_;
+} dodt_layer_info;
+int dodt_extractor_layer_count(const dodt_extractor* ex);
+int dodt_extractor_forward_timed(dodt_extractor* ex, const float* d_in, float* d_feat_out,
+                                 float* d_bottleneck_out, dodt_layer_info* info, int n_info);
 
 /* ---- a11: ROI crop ------------------------------------------------------------------
  * tf.image.crop_and_resize(image, boxes, box_ind=0, crop_size) call sites

@@ -35,38 +35,57 @@ def round_bf16(x):
     return r.view(F32)
 
 
+# Arithmetic of the conv / transposed-conv sums.  F32: the reference's (float32 throughout, one
+# sgemm per tap).  np.float64 ("exact" mode, set through `exact_sums`): every sum in float64 and ONE
+# rounding per layer -- not the reference's arithmetic but the value every legal float32 evaluation
+# order scatters around; tests use it to measure how far such orders drift apart end to end.
+ACC = F32
+
+
+class exact_sums(object):
+    """with tfops.exact_sums(): conv sums in float64, rounded once per layer."""
+
+    def __enter__(self):
+        global ACC
+        self._old, ACC = ACC, np.float64
+
+    def __exit__(self, *exc):
+        global ACC
+        ACC = self._old
+
+
 def conv2d_same(x, w):
     """x (H,W,Cin), w (kh,kw,Cin,Cout) -> (H,W,Cout); stride 1, SAME.
     Accumulates tap by tap in float32 (one GEMM per tap)."""
-    x = np.asarray(x, dtype=F32)
-    w = np.asarray(w, dtype=F32)
+    x = np.asarray(x, dtype=F32).astype(ACC)
+    w = np.asarray(w, dtype=F32).astype(ACC)
     kh, kw, cin, cout = w.shape
     h, wd, _ = x.shape
     pt, pl = (kh - 1) // 2, (kw - 1) // 2
-    xp = np.zeros((h + kh - 1, wd + kw - 1, cin), dtype=F32)
+    xp = np.zeros((h + kh - 1, wd + kw - 1, cin), dtype=ACC)
     xp[pt:pt + h, pl:pl + wd] = x
-    out = np.zeros((h * wd, cout), dtype=F32)
+    out = np.zeros((h * wd, cout), dtype=ACC)
     for ky in range(kh):
         for kx in range(kw):
             patch = np.ascontiguousarray(xp[ky:ky + h, kx:kx + wd]).reshape(-1, cin)
             out += patch @ w[ky, kx]
-    return out.reshape(h, wd, cout)
+    return out.reshape(h, wd, cout).astype(F32)
 
 
 def conv2d_transpose_s2_same(x, w):
     """x (H,W,Cin), w (3,3,Cout,Cin) -> (2H,2W,Cout); stride 2, SAME.
     Gradient-of-conv form: out[2i+ky, 2j+kx] += x[i,j] @ w[ky,kx].T."""
-    x = np.asarray(x, dtype=F32)
-    w = np.asarray(w, dtype=F32)
+    x = np.asarray(x, dtype=F32).astype(ACC)
+    w = np.asarray(w, dtype=F32).astype(ACC)
     kh, kw, cout, cin = w.shape
     h, wd, _ = x.shape
-    big = np.zeros((2 * h + 2, 2 * wd + 2, cout), dtype=F32)
+    big = np.zeros((2 * h + 2, 2 * wd + 2, cout), dtype=ACC)
     flat = x.reshape(-1, cin)
     for ky in range(kh):
         for kx in range(kw):
             contrib = (flat @ w[ky, kx].T).reshape(h, wd, cout)
             big[ky:ky + 2 * h:2, kx:kx + 2 * wd:2] += contrib
-    return big[:2 * h, :2 * wd]
+    return big[:2 * h, :2 * wd].astype(F32)
 
 
 def bn_scale_shift(beta, mean, var):
