@@ -49,6 +49,9 @@ def parse():
     ap.add_argument('--no-alt', action='store_true',
                     help='skip the short extra run with the other conv arithmetic')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather-every', type=int, default=8,
+                    help='steps whose detection records travel in one all-gather (the temporal module '
+                         'consumes them in sequence order whenever they arrive; fewer, larger messages)')
     ap.add_argument('--comm', action='store_true',
                     help='make an RCCL communicator even with one rank (exercises the exchange '
                          'step on a single GPU)')
@@ -213,6 +216,11 @@ def main():
         # first, while the GPU is still untouched: the workers are spawned processes
         baseline = cpu_baseline(args.heads == 'computed', args.cpu_pairs)
 
+    if world > 1 or args.comm:
+        # the exchange step's side stream is a fifth stream: give the process more than ROCm's
+        # default of four hardware queues, or it shares one with a compute stream (measured on one
+        # GPU with a 1-rank communicator: 244 -> 263 pairs/s at one gather per step)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     from dodt_amd import _lib, config, device, ops, sharding, synth
     from dodt_amd.pipeline import (CORR_CH, CORR_MAX_DISP, CORR_PAD, CORR_STRIDE2, MAX_DET, REC_COLS,
                                    ROI, FramePairPipeline)
@@ -238,12 +246,21 @@ def main():
                                  conv_dtype=conv_dtype, head_dtype=head_dtype,
                                  reuse_streams_of=made[0] if made and min(made[0].nf, 2) == min(fps * pps, 2) else None)
         made.append(pipe)
-        # what the exchange step fills: every rank's records of a step, by step parity
-        gathered = [ctx.zeros((world * pps, fps, MAX_DET, REC_COLS), np.float32) for _ in range(2)]
-        gathered_cnt = [ctx.zeros((world * pps, fps), np.int32) for _ in range(2)]
+        # The exchange step ships G consecutive steps' records in one all-gather: the pipeline
+        # writes step k into slot k % 2G of a contiguous ring, and a half of the ring (a block of G
+        # steps) is one message.  gathered[b]: every rank's block, rank major.
+        G = max(1, args.gather_every)
+        rec_ring = ctx.zeros((2 * G, pps, fps, MAX_DET, REC_COLS), np.float32)
+        cnt_ring = ctx.zeros((2 * G, pps, fps), np.int32)
+        pipe.use_record_ring(rec_ring, cnt_ring)
+        nr, nc = 4 * pps * fps * MAX_DET * REC_COLS, 4 * pps * fps
+        blocks = [(rec_ring.offset(b * G * nr, (G * pps, fps, MAX_DET, REC_COLS)),
+                   cnt_ring.offset(b * G * nc, (G * pps, fps), np.int32)) for b in range(2)]
+        gathered = [ctx.zeros((world * G * pps, fps, MAX_DET, REC_COLS), np.float32) for _ in range(2)]
+        gathered_cnt = [ctx.zeros((world * G * pps, fps), np.int32) for _ in range(2)]
         if comm is not None:
-            # the tail that refills a record buffer first joins the gather that last read it
-            pipe.on_records_reuse = lambda par, sides: [comm.join(par, s) for s in sides]
+            # the tail that refills a slot first joins the gather that last read its block
+            pipe.on_records_reuse = lambda slot, sides: [comm.join(slot // G, s) for s in sides]
 
         # a small ring of distinct synthetic batches, resident in HBM before timing starts;
         # every pair of a batch comes from a different sequence (they are independent)
@@ -272,32 +289,34 @@ def main():
                     b['h_imgs'].append(hi)
             batches.append(b)
 
-        state = {'n': 0, 'par': 0}
+        state = {'sent': 0, 'last_block': None}     # steps whose records have been shipped
 
-        def gather(par):
+        def gather_block(b):
             # on the communicator's side stream, behind what the main stream holds so far (the
-            # records of that step are complete there: FramePairPipeline.run); nothing waits for
-            # it until that record buffer is written again two steps later
+            # records of the block's steps are complete there: FramePairPipeline.run / finish);
+            # nothing waits for it until the block's first slot is written again, G + 1 steps later
             if comm is not None:
-                comm.all_gather_records(ctx, par, pipe.rec2[par], pipe.cnt2[par], gathered[par],
-                                        gathered_cnt[par])
+                comm.all_gather_records(ctx, b, blocks[b][0], blocks[b][1], gathered[b], gathered_cnt[b])
+                state['last_block'] = b
+
+        def ship(complete):      # records of steps < complete are complete on the main stream
+            while state['sent'] + G <= complete:
+                gather_block((state['sent'] // G) % 2)
+                state['sent'] += G
 
         def step(i):
             p = batches[i % n_batches]
             if from_host:
-                par = pipe.run_from_host(p['h_pts'], p['n'], p['h_imgs'], p['heads'])
+                pipe.run_from_host(p['h_pts'], p['n'], p['h_imgs'], p['heads'])
             else:
-                par = pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
-            if state['n'] > 0:     # records of the previous step are complete on the main stream
-                gather(1 - par)
-            state['n'] += 1
-            state['par'] = par
+                pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
+            ship(pipe.step_idx - 1)
 
         def drain():
             pipe.finish()
-            if state['n'] > 0:
-                gather(state['par'])
-            state['n'] = 0
+            ship(pipe.step_idx)
+            if state['sent'] < pipe.step_idx:       # a block that is not full yet: ship it as it is
+                gather_block((state['sent'] // G) % 2)
 
         def barrier():
             ctx.sync()                  # finish() joined every stream of the pipeline into this one
@@ -335,11 +354,11 @@ def main():
                    flops=pipe.flops_per_step(), mfma_flops=pipe.mfma_flops_per_step(),
                    head_gflop=pipe.head_flops_per_step() / 1e9, conv_bytes=pipe.conv_bytes_per_step(),
                    anchors=list(pipe.last_anchor_counts), steps=steps, pps=pps)
-        if comm is not None and rank == 0:
-            # the exchange really happened: rank 0's own block of the last gather equals its records
-            par = state['par']
-            g = gathered[par].download()[rank * pps:(rank + 1) * pps]
-            res['gather_ok'] = bool(np.array_equal(g, pipe.rec2[par].download()))
+        if comm is not None and rank == 0 and state['last_block'] is not None:
+            # the exchange really happened: rank 0's own part of the last message equals its records
+            b = state['last_block']
+            g = gathered[b].download()[rank * G * pps:(rank + 1) * G * pps]
+            res['gather_ok'] = bool(np.array_equal(g, blocks[b][0].download()) and np.abs(g).max() > 0)
 
         # ---- the conv stacks alone (each net by itself on its own stream, so that kernel
         #      durations do not overlap), layer by layer: HIP events on the stream the kernels run on
@@ -382,7 +401,7 @@ def main():
             # ---- the HBM-bound kernels alone, on the inputs the last step left behind -----------
             if fps == 2 and computed and cfg['extractor'] != 'vgg':
                 hreps = 20
-                fr, feat = pipe.fr, pipe.feat[state['par']]
+                fr, feat = pipe.fr, pipe.feat[(pipe.step_idx - 1) & 1]
                 n_pts = batches[0]['n'][0]
 
                 def timed(fn):
@@ -563,8 +582,9 @@ def main():
                         % (args.points // 1000, args.proposals)),
                        'head_gflop_per_step': round(m['head_gflop'], 2),
                        'pairs_per_step_per_gpu': pps, 'parallelism': 'pair-shard x%d' % world,
-                       'exchange': ('RCCL all-gather of (pairs,2,100,17) f32 + counts per step, side stream, '
-                                    'C-ABI (no PyTorch)%s' % ('; rank 0 block verified' if m.get('gather_ok') else '')
+                       'exchange': ('RCCL all-gather of (%d steps x pairs,2,100,17) f32 + counts every %d steps, side '
+                                    'stream, C-ABI (no PyTorch)%s' % (max(1, args.gather_every), max(1, args.gather_every),
+                                                                     "; rank 0's part verified" if m.get('gather_ok') else '')
                                     ) if comm is not None else 'none (one rank)',
                        'conv_mode': os.environ.get('DODT_CONV_WINO', 'default'),
                        'anchors_kept': m['anchors']},

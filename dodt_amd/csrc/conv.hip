@@ -100,10 +100,12 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     int best = -1;
     double best_cost = 1e300;
     // fp32 3x3 stride-1 convs with >= 4 chunks of input channels run as Winograd.
-    // DODT_CONV_WINO: 4 (default) = F(4x4,3x3) (wino43_kernel.h: 4x fewer fp32 MFMA cycles than the
-    // direct form; both stacks 2.7 ms), 2 = F(2x2,3x3) with 128 accumulators, two workgroups per CU
-    // (wino_kernels.h: 3.0 ms), 1 = its 256-accumulator variants, one workgroup per CU (no faster
-    // than direct), 0 = the direct kernels (4.8 ms).
+    // dodt_conv_mode(): 2 (default) = F(2x2,3x3) with 128 accumulators, two workgroups per CU
+    // (wino_kernels.h: both stacks 3.0 ms, rounding noise at the direct kernels' level), 4 =
+    // F(4x4,3x3) (wino43_kernel.h: 2.7 ms, but its fp32 accumulation in the transformed domain is
+    // 20x noisier, which halves the end-to-end agreement with the exact result: opt-in), 1 = the
+    // 256-accumulator F(2x2) variants, one workgroup per CU (no faster than direct), 0 = the direct
+    // kernels (4.8 ms).
     static const int wino_mode = dodt_conv_mode();
     if (wino_mode > 0 && !deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
         for (size_t i = 0; i < vs.size(); ++i) {

@@ -177,14 +177,16 @@ class FramePairPipeline(object):
         self.fr = self.fr2[0]          # buffers of the most recently finished step
         self.step_idx = 0
         self.pending = None            # step whose tail has not been enqueued yet
-        # detection records of a step: what the all-gather ships; by step parity
+        # detection records of a step: what the all-gather ships.  A ring of R >= 2
+        # buffers, step k fills slot k % R (R = 2: by step parity); use_record_ring() makes it
+        # longer so that the exchange step can ship several steps at once
         self.rec2 = [ctx.empty((self.pairs, self.fps, MAX_DET, REC_COLS), f32) for _ in range(2)]
         self.cnt2 = [ctx.zeros((self.pairs, self.fps), i32) for _ in range(2)]
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]   # last finished step
         self.last_anchor_counts = [0] * self.nf
-        # hook(parity, side contexts), called before a tail refills the record buffers of that
-        # parity: the exchange step (sharding.Communicator.join) makes the tails wait for the
-        # all-gather that last read them, two steps earlier
+        # hook(slot, side contexts), called before a tail refills record slot `slot`: the exchange
+        # step (sharding.Communicator.join) makes the tails wait for the all-gather that last
+        # read it, at least a ring's half earlier
         self.on_records_reuse = None
         self.mark_steps = ()           # tools/pipe_marks.py: steps whose stages get timing marks
         self.marks = {}                # name -> (context, slot)
@@ -223,11 +225,24 @@ class FramePairPipeline(object):
 
     def use_record_buffers(self, rec_ptrs, cnt_ptrs):
         """Write detection records into caller-owned device memory (e.g. buffers registered with
-        a communication library): two of each, used by step parity."""
+        a communication library): R >= 2 of each, step k fills number k % R."""
+        if len(rec_ptrs) < 2 or len(rec_ptrs) != len(cnt_ptrs):
+            raise ValueError('use_record_buffers: at least two record and count buffers, as many of each')
         self.rec2 = [self.ctx.wrap(p, (self.pairs, self.fps, MAX_DET, REC_COLS), np.float32)
                      for p in rec_ptrs]
         self.cnt2 = [self.ctx.wrap(p, (self.pairs, self.fps), np.int32) for p in cnt_ptrs]
         self.d_records, self.d_rec_counts = self.rec2[0], self.cnt2[0]
+
+    def use_record_ring(self, d_rec_ring, d_cnt_ring):
+        """The same with one contiguous ring: d_rec_ring (R, pairs, fps, MAX_DET, REC_COLS) float32,
+        d_cnt_ring (R, pairs, fps) int32 -- so that any run of consecutive slots is one message."""
+        R = d_rec_ring.shape[0]
+        if tuple(d_rec_ring.shape[1:]) != (self.pairs, self.fps, MAX_DET, REC_COLS) or \
+                tuple(d_cnt_ring.shape) != (R, self.pairs, self.fps):
+            raise ValueError('use_record_ring: shapes do not match the pipeline')
+        nr, nc = 4 * self.pairs * self.fps * MAX_DET * REC_COLS, 4 * self.pairs * self.fps
+        self.use_record_buffers([d_rec_ring.ptr + nr * i for i in range(R)],
+                                [d_cnt_ring.ptr + nc * i for i in range(R)])
 
     # ------------------------------------------------------------------------------------
     def run_from_host(self, h_points, n_points, h_images, heads=None, ego_motion=None):
@@ -317,7 +332,7 @@ class FramePairPipeline(object):
             for i, s in enumerate(self.sides):
                 main.wait_for(s)       # previous step's records are complete on `main`
                 self.preps[i].wait_for(s)   # the NEXT step's prep reuses that tail's buffers
-        self.pending = dict(cur=cur, heads=heads, step=k)
+        self.pending = dict(cur=cur, heads=heads, step=k, rslot=k % len(self.rec2))
         # the tail of THIS step (next call) starts when these convs are done
         for s in self.sides:
             s.wait_for(main)
@@ -346,7 +361,7 @@ class FramePairPipeline(object):
                   for f in range(nf)]
         self.last_anchor_counts = counts
         self.fr = fr
-        self.d_records, self.d_rec_counts = self.rec2[cur], self.cnt2[cur]
+        self.d_records, self.d_rec_counts = self.rec2[st['rslot']], self.cnt2[st['rslot']]
         self.d_bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w,
                                                        self.cfg['bev_depth']))
         bev_px = self.bev_fh * self.bev_fw
@@ -357,7 +372,7 @@ class FramePairPipeline(object):
         if os.environ.get('DODT_PIPE_NO_TAIL'):      # (tools/: the step without its tail)
             return
         if self.on_records_reuse is not None:
-            self.on_records_reuse(cur, self.sides)
+            self.on_records_reuse(st['rslot'], self.sides)
         for f in range(nf):
             c, b, A = self.sides[f % ns], fr[f], counts[f]
             computed = heads is None

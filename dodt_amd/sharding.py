@@ -126,6 +126,17 @@ def rendezvous_path(env=None):
     return os.path.join(env.get('TMPDIR', '/tmp'), 'dodt_rccl_id_%s' % key)
 
 
+def merge_block(gathered, gathered_cnt, first_step, n_steps, pairs_per_step, world):
+    """Records of `n_steps` consecutive steps shipped as one message (each rank's block is
+    (n_steps, pairs_per_step, 2, ...), step major) in global pair order."""
+    g = np.asarray(gathered).reshape(world, n_steps, pairs_per_step, 2, MAX_DET, REC_COLS)
+    c = np.asarray(gathered_cnt).reshape(world, n_steps, pairs_per_step, 2)
+    out = []
+    for i in range(n_steps):
+        out += merge_step(g[:, i], c[:, i], first_step + i, pairs_per_step, world)
+    return out
+
+
 def merge_step(gathered, gathered_cnt, step, pairs_per_step, world):
     """Records of one step in global pair order: list of (pair_id, frame, (n,17) array)."""
     g = np.asarray(gathered).reshape(world, pairs_per_step, 2, MAX_DET, REC_COLS)

@@ -219,7 +219,7 @@ typedef struct dodt_extractor dodt_extractor;
  * fp32 throughout and within the 1e-4 layer bar; they differ in speed and in how far the rounding
  * noise of a whole stack lies from the exact sums (DESIGN.md 2 / 5.0 give both, and the rule that
  * chose the default).  DODT_CONV_WINO in the environment overrides the default, once per process. */
-#define DODT_CONV_MODE_DEFAULT 4
+#define DODT_CONV_MODE_DEFAULT 2
 int dodt_conv_mode(void);
 /* in_c: channels of the input tensor as stored (6 for BEV; 4 for the padded
  * image); pad_top: zero rows added on top (4 for BEV 700->704, 0 for images);

@@ -124,14 +124,14 @@ def test_extractor_errors():
         ex2.build(np.zeros((1, 28, 40, 6), np.float32), is_training=True)
 
 
-@pytest.mark.parametrize('mode', ['0', '1', '2'])
+@pytest.mark.parametrize('mode', ['0', '1', '2', '4'])
 def test_other_fp32_conv_paths_match_oracle(mode):
-    """The default fp32 path of the 3x3 stride-1 layers is the Winograd F(4x4,3x3) kernel
-    (DODT_CONV_WINO=4, what every other test in this file runs; its error against the oracle is
-    3-5e-6 of a layer's scale, the bar 1e-4).  The direct implicit-GEMM kernels (0), the
-    F(2x2,3x3) kernel with 128 accumulators (2) and its 256-accumulator variants (1) stay
-    selectable through the environment, which the library reads once per process: they are
-    checked in a child process against the same oracle at the same 1e-4 bar."""
+    """Every form of the fp32 3x3 stride-1 layers against the same oracle at the same 1e-4 bar, each
+    in a child process (the library reads DODT_CONV_WINO once per process): the direct implicit-GEMM
+    kernels (0), Winograd F(2x2,3x3) with 128 accumulators (2: the default, what every other test
+    in this file runs) and its 256-accumulator variants (1), Winograd F(4x4,3x3) (4: the fastest;
+    3-5e-6 of a layer's scale from the oracle where the others are at 2e-7, which is why it is not
+    the default -- tests/test_gpu_heads.py::test_pair_free_running_by_conv_mode)."""
     import os
     import subprocess
     import sys
