@@ -541,7 +541,11 @@ def main():
                          algorithmic_mbytes=round(m['conv_bytes'] / 1e6, 1),
                          side_by_side_ms=round(m['both_ms'], 4),
                          side_by_side_direct_equivalent_tflops=round(m['flops'] / (m['both_ms'] * 1e-3) / 1e12, 2)),
-        kernels=kernels)
+        kernels=kernels,
+        layers=[dict(net='bev' if i < len(m['layers']) // 2 else 'img', name=l['name'], kernel=l['kernel'],
+                     items=l['items'], us=round(l['ms'] * 1e3, 1),
+                     executed_tflops=round(l['flops_executed'] / (l['ms'] * 1e-3) / 1e12, 1))
+                for i, l in enumerate(m['layers'])])
     hbm = m.get('hbm')
     if hbm:
         hj = _profile_json('r3_hbm_traffic.json')

@@ -15,10 +15,22 @@ class EarlyFusionFcLayers(object):
     pyramid_cars_with_aug_dt_5_tracking.config:29), ('cls_out', 'off_out') for box_4c / box_8c,
     ('off_out',) for the corr head."""
 
+    K_ALIGN = 32     # the LDS-DMA GEMM walks K in stages of 32 (csrc/gemm.hip: fc_dma_kernel)
+
     def __init__(self, ctx, params, outputs=('cls_out', 'off_out', 'ang_out'), dtype='f32'):
         names = sorted(k for k in params if k.startswith('fc'))
-        self.hidden = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], True, dtype=dtype)
-                       for k in names]
+        # The first layer's K is the flattened crop (7*7*32 = 1568 for the fusion head, 7*7*25 = 1225
+        # for the correlation head).  A K that is no multiple of 32 would keep that GEMM on the
+        # register-staged kernel: its weights get zero rows up to the next multiple and the crops are
+        # written as rows of `in_ld` floats whose tail stays zero (FramePairPipeline allocates them
+        # zeroed; the crop kernel never touches the pad) -- the same sums, + 0 * 0 terms.
+        w0 = np.asarray(params[names[0]]['w'], np.float32)
+        self.in_k = w0.shape[0]
+        self.in_ld = -(-self.in_k // self.K_ALIGN) * self.K_ALIGN
+        if self.in_ld != self.in_k:
+            w0 = np.concatenate([w0, np.zeros((self.in_ld - self.in_k, w0.shape[1]), np.float32)], 0)
+        self.hidden = [ops.FullyConnected(ctx, w0 if k == names[0] else params[k]['w'], params[k]['b'],
+                                          True, dtype=dtype) for k in names]
         self.outputs = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], False, dtype=dtype)
                         for k in outputs]
         self.width = max(l.N for l in self.hidden)
@@ -29,9 +41,10 @@ class EarlyFusionFcLayers(object):
         return [self.ctx.empty((n_max, self.width), np.float32) for _ in range(2)]
 
     def forward(self, ctx, d_rois, d_rois2, n, d_n, d_outs, scratch):
-        """d_rois (n,h,w,c) [and d_rois2, fused by mean]; *d_n rows are valid;
+        """d_rois: n rows of `in_ld` floats, the flattened (h,w,c) crop in front and zeros behind it
+        (= (n,h,w,c) when in_ld == h*w*c) [and d_rois2, fused by mean]; *d_n rows are valid;
         d_outs: one (n, size) array per output layer."""
-        x, x2, ldx = d_rois, d_rois2, None
+        x, x2, ldx = d_rois, d_rois2, self.in_ld
         for i, l in enumerate(self.hidden):
             y = scratch[i & 1]
             l.forward(x, n, y, ldx=ldx, ldy=self.width, d_x2=x2, d_m=d_n, ctx=ctx)
@@ -40,7 +53,9 @@ class EarlyFusionFcLayers(object):
             l.forward(x, n, d_y, ldx=ldx, d_m=d_n, ctx=ctx)
 
     def flops(self, n):
-        return sum(l.flops(n) for l in self.hidden + self.outputs)
+        """Of the layers as the reference defines them (the zero rows of a padded K do not count)."""
+        return sum(l.flops(n) for l in self.hidden + self.outputs) \
+            - 2.0 * n * (self.in_ld - self.in_k) * self.hidden[0].N
 
     def close(self):
         for l in self.hidden + self.outputs:

@@ -14,7 +14,8 @@ namespace {
 template <int VEC>
 __global__ void __launch_bounds__(256)
 crop_kernel(const float* __restrict__ img, int H, int W, int C, const float* __restrict__ boxes,
-            int n, const int* __restrict__ d_n, int ch, int cw, float* __restrict__ out) {
+            int n, const int* __restrict__ d_n, int ch, int cw, float* __restrict__ out,
+            long long out_stride) {
     const int groups = C / VEC;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lim = d_n ? min(*d_n, n) : n;
@@ -32,7 +33,7 @@ crop_kernel(const float* __restrict__ img, int H, int W, int C, const float* __r
     const float ws = (cw > 1) ? (x2 - x1) * wm1 / (float)(cw - 1) : 0.0f;
     const float in_y = (ch > 1) ? y1 * hm1 + (float)iy * hs : 0.5f * (y1 + y2) * hm1;
     const float in_x = (cw > 1) ? x1 * wm1 + (float)ix * ws : 0.5f * (x1 + x2) * wm1;
-    float* o = out + ((((size_t)b * ch + iy) * cw + ix) * C + (size_t)g * VEC);
+    float* o = out + (size_t)b * out_stride + (((size_t)iy * cw + ix) * C + (size_t)g * VEC);
     const bool ok = (in_y >= 0.0f) && (in_y <= hm1) && (in_x >= 0.0f) && (in_x <= wm1);
     if (!ok) {  // also catches NaN coordinates
 #pragma unroll
@@ -60,20 +61,30 @@ crop_kernel(const float* __restrict__ img, int H, int W, int C, const float* __r
 extern "C" int dodt_crop_and_resize(dodt_ctx* ctx, const float* d_image, int H, int W, int C,
                                     const float* d_boxes, int n, const int32_t* d_n, int crop_h,
                                     int crop_w, float* d_out) {
+    return dodt_crop_and_resize_strided(ctx, d_image, H, W, C, d_boxes, n, d_n, crop_h, crop_w, d_out,
+                                        (long long)crop_h * crop_w * C);
+}
+
+extern "C" int dodt_crop_and_resize_strided(dodt_ctx* ctx, const float* d_image, int H, int W, int C,
+                                            const float* d_boxes, int n, const int32_t* d_n, int crop_h,
+                                            int crop_w, float* d_out, long long out_box_stride) {
     DODT_REQUIRE(ctx && d_image && d_out && (n == 0 || d_boxes),
                  "dodt_crop_and_resize: NULL argument");
     DODT_REQUIRE(H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && n >= 0,
                  "dodt_crop_and_resize: bad sizes");
+    DODT_REQUIRE(out_box_stride >= (long long)crop_h * crop_w * C,
+                 "dodt_crop_and_resize: output stride %lld shorter than a crop", out_box_stride);
     if (n == 0) return DODT_OK;
-    const int vec = (C % 4 == 0) ? 4 : 1;
+    // float4 stores need 16-byte aligned crops
+    const int vec = (C % 4 == 0 && out_box_stride % 4 == 0) ? 4 : 1;
     const long long total = (long long)n * crop_h * crop_w * (C / vec);
     const int blocks = (int)((total + 255) / 256);
     if (vec == 4)
         hipLaunchKernelGGL(crop_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, d_image, H, W,
-                           C, d_boxes, n, d_n, crop_h, crop_w, d_out);
+                           C, d_boxes, n, d_n, crop_h, crop_w, d_out, out_box_stride);
     else
         hipLaunchKernelGGL(crop_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_image, H, W,
-                           C, d_boxes, n, d_n, crop_h, crop_w, d_out);
+                           C, d_boxes, n, d_n, crop_h, crop_w, d_out, out_box_stride);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
 }

@@ -102,10 +102,13 @@ def img_preprocess(ctx, d_img_u8, in_hw, out_hw, out_c, mean_rgb, d_out):
         'dodt_img_preprocess')
 
 
-def crop_and_resize(ctx, d_image, hwc, d_boxes, n, d_n, crop_hw, d_out):
-    _lib.check(ctx.lib.dodt_crop_and_resize(
+def crop_and_resize(ctx, d_image, hwc, d_boxes, n, d_n, crop_hw, d_out, out_box_stride=None):
+    """out_box_stride (floats): box b's crop starts at d_out + b * out_box_stride (default: packed)."""
+    if out_box_stride is None:
+        out_box_stride = int(crop_hw[0]) * int(crop_hw[1]) * int(hwc[2])
+    _lib.check(ctx.lib.dodt_crop_and_resize_strided(
         ctx.handle, _p(d_image), int(hwc[0]), int(hwc[1]), int(hwc[2]), _p(d_boxes),
-        int(n), _p(d_n), int(crop_hw[0]), int(crop_hw[1]), _p(d_out)),
+        int(n), _p(d_n), int(crop_hw[0]), int(crop_hw[1]), _p(d_out), int(out_box_stride)),
         'dodt_crop_and_resize')
 
 

@@ -171,7 +171,8 @@ class FramePairPipeline(object):
                 if self.box_4ca:
                     b.update(angle_vectors=ctx.empty((P, 2), f32))
                 if self.fps == 2 and f % 2 == 0:
-                    b.update(corr_rois=ctx.empty((P, ROI, ROI, CORR_CH), f32),
+                    # rows of the correlation head's padded K (zeros behind each 7x7x25 crop)
+                    b.update(corr_rois=ctx.zeros((P, self.corr_head.in_ld), f32),
                              corr_offsets=ctx.empty((P, 3), f32))
             self.fr2[f // self.nf].append(b)
         self.fr = self.fr2[0]          # buffers of the most recently finished step
@@ -428,7 +429,7 @@ class FramePairPipeline(object):
                                     CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD, scratch['corr_map'])
                     ops.crop_and_resize(c, scratch['corr_map'], bev_hw + (CORR_CH,),
                                         b['top_bev'], self.P, b['top_count'], (ROI, ROI),
-                                        b['corr_rois'])
+                                        b['corr_rois'], out_box_stride=self.corr_head.in_ld)
                     self._mark(c, st['step'], 'tail%d_corrmap' % f)
                     self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
                                            [b['corr_offsets']], scratch['fc'])

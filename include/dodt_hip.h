@@ -291,6 +291,13 @@ int dodt_extractor_forward_timed(dodt_extractor* ex, const float* d_in, float* d
 int dodt_crop_and_resize(dodt_ctx* ctx, const float* d_image, int H, int W, int C,
                          const float* d_boxes, int n, const int32_t* d_n, int crop_h,
                          int crop_w, float* d_out);
+/* The same with box b's crop written at d_out + b * out_box_stride floats (>= ch*cw*C; the floats
+ * between crops are left untouched): the flattened crops become rows of a matrix whose row length is
+ * padded for the fully connected layer that reads them (the correlation head's fc6 has K = 7*7*25 =
+ * 1225; rows of 1248 zero-padded floats let it run on the LDS-DMA GEMM). */
+int dodt_crop_and_resize_strided(dodt_ctx* ctx, const float* d_image, int H, int W, int C,
+                                 const float* d_boxes, int n, const int32_t* d_n, int crop_h,
+                                 int crop_w, float* d_out, long long out_box_stride);
 
 /* ---- T branch: correlation of the two frames' BEV feature maps ------------------------
  * Stands behind avod/core/corr_layers/correlation.py:7-27 -> the Correlation custom op

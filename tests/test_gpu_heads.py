@@ -177,7 +177,9 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
         _close(heads['angle_vectors'], ang, tol)      # box_4ca's third output layer
         if f == 0:
             want_rois = tfops.crop_and_resize(corr_map, b['top_bev'].download()[:n_top], 7, 7)
-            got_rois = b['corr_rois'].download()[:n_top]
+            rows = b['corr_rois'].download()[:n_top]        # rows padded to the head's K (zeros)
+            assert rows.shape[1] == pipe.corr_head.in_ld and not rows[:, 7 * 7 * CORR_CH:].any()
+            got_rois = rows[:, :7 * 7 * CORR_CH].reshape(n_top, 7, 7, CORR_CH)
             _close(got_rois, want_rois, 5e-4)
             heads['corr_offsets'] = b['corr_offsets'].download()[:n_top]
             _close(heads['corr_offsets'], oheads.corr_fc_early(got_rois, hp['corr'], head_dtype), tol)
