@@ -313,6 +313,10 @@ int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
 //     running fastest: its workgroups share x rows and sweep K together, so most fills hit its L2
 //     (fill rate from L2 ~50 B/clk/CU against ~10.5 from beyond it, tools/micro/fill_rate.hip).
 // Needs K % 32 == 0, ldx % 4 == 0 (16-byte aligned rows) and the 128-wide weight blocking.
+// (Round 3 tried a FOUR-stage ring, 64 KB and still two workgroups per CU, in which a wave reads the
+//  fragments of stage s + 1 under the MFMAs of stage s instead of behind the barrier: 103 TFLOP/s against
+//  this form's 109 at M = 1024, N = K = 2048 -- the LDS latency in front of the MFMAs is not what is
+//  left; removed again.)
 constexpr int kDmaBM = 64, kDmaBK = 32, kDmaStages = 3;
 constexpr int kDmaXFloats = kDmaBM * kDmaBK;
 

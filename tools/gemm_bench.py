@@ -11,7 +11,7 @@ from dodt_amd import device, ops  # noqa: E402
 ctx = device.default_context()
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 rng = np.random.default_rng(0)
-for M, K, N in [(1024, 1568, 2048), (1024, 2048, 2048), (1024, 1225, 2048), (1024, 2048, 10),
+for M, K, N in [(1024, 1568, 2048), (1024, 2048, 2048), (1024, 1225, 2048), (1024, 1248, 2048), (1024, 2048, 10),
                 (5500, 9, 512), (5500, 256, 256), (5500, 256, 6), (2048, 1568, 2048), (2048, 2048, 2048), (4096, 2048, 2048)]:
     x = ctx.array(rng.normal(size=(M, K)).astype(np.float32))
     fc = ops.FullyConnected(ctx, rng.normal(size=(K, N)).astype(np.float32),
