@@ -216,11 +216,6 @@ def main():
         # first, while the GPU is still untouched: the workers are spawned processes
         baseline = cpu_baseline(args.heads == 'computed', args.cpu_pairs)
 
-    if world > 1 or args.comm:
-        # the exchange step's side stream is a fifth stream: give the process more than ROCm's
-        # default of four hardware queues, or it shares one with a compute stream (measured on one
-        # GPU with a 1-rank communicator: 244 -> 263 pairs/s at one gather per step)
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     from dodt_amd import _lib, config, device, ops, sharding, synth
     from dodt_amd.pipeline import (CORR_CH, CORR_MAX_DISP, CORR_PAD, CORR_STRIDE2, MAX_DET, REC_COLS,
                                    ROI, FramePairPipeline)

@@ -1,9 +1,18 @@
 """Device context and device arrays over the C-ABI (no PyTorch)."""
 import ctypes as C
+import os
 
 import numpy as np
 
 from dodt_amd import _lib
+
+
+# ROCm maps a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The frame-pair
+# pipeline runs four streams (two conv stacks, two frames' prep + tail) and the multi-GPU exchange step
+# adds a fifth: a stream that shares a queue runs behind the other's launches (measured with a 1-rank
+# communicator: 247 pairs/s on four queues, 280 on eight, 284 without the fifth stream).  Read by the HIP
+# runtime when it initialises, i.e. at the first Context of the process.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
 class DeviceArray(object):
