@@ -224,7 +224,19 @@ def main():
         ctx = device.Context(local_rank)
     except _lib.DodtError as e:
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path (%s)' % e)
-    comm = sharding.Communicator(ctx, rank, world) if (world > 1 or args.comm) else None
+    comm, host_sync, comm_error = None, None, None
+    if world > 1 or args.comm:
+        try:
+            comm = sharding.Communicator(ctx, rank, world)
+        except Exception as e:      # RCCL missing or the ranks could not meet
+            if world == 1:
+                raise
+            # Degraded mode, said loudly in config.exchange: the ranks still keep the timing protocol
+            # (barriers and max over ranks through files), but NO records are exchanged
+            comm_error = '%s: %s' % (type(e).__name__, e)
+            sys.stderr.write('[bench] rank %d: RCCL exchange unavailable (%s); host barrier only\n'
+                             % (rank, comm_error))
+            host_sync = sharding.HostBarrier(rank, world)
     computed = args.heads == 'computed'
     made = []   # pipelines built so far: later ones reuse the first one's streams
 
@@ -317,6 +329,8 @@ def main():
             ctx.sync()                  # finish() joined every stream of the pipeline into this one
             if comm is not None:
                 comm.barrier()          # drains the side stream, then all ranks meet
+            elif host_sync is not None:
+                host_sync.barrier()
 
         # steps are pipelined two deep inside pipe.run(); finish() drains the last one, so
         # exactly `steps` complete steps (convs AND tails) lie inside the timed region
@@ -345,6 +359,8 @@ def main():
         step_ms = [ctx.elapsed_ms(i, ctx, i + 1) for i in range(n_ev + 1)]
         if comm is not None:
             elapsed = comm.max_over_ranks(elapsed)
+        elif host_sync is not None:
+            elapsed = host_sync.max_over_ranks(elapsed)
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, step_ms=step_ms, host_ms=host_ms,
                    flops=pipe.flops_per_step(), mfma_flops=pipe.mfma_flops_per_step(),
                    head_gflop=pipe.head_flops_per_step() / 1e9, conv_bytes=pipe.conv_bytes_per_step(),
@@ -584,7 +600,8 @@ def main():
                        'exchange': ('RCCL all-gather of (%d steps x pairs,2,100,17) f32 + counts every %d steps, side '
                                     'stream, C-ABI (no PyTorch)%s' % (max(1, args.gather_every), max(1, args.gather_every),
                                                                      "; rank 0's part verified" if m.get('gather_ok') else '')
-                                    ) if comm is not None else 'none (one rank)',
+                                    ) if comm is not None else ('none (one rank)' if comm_error is None else
+                                                               'FAILED, no records exchanged, host barrier only: ' + comm_error),
                        'conv_mode': os.environ.get('DODT_CONV_WINO', 'default'),
                        'anchors_kept': m['anchors']},
             'roofline': roofline,
@@ -598,6 +615,8 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+    if host_sync is not None:
+        host_sync.close()
 
 
 if __name__ == '__main__':

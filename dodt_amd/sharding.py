@@ -115,6 +115,57 @@ class Communicator(object):
                 pass
 
 
+class HostBarrier(object):
+    """Degraded stand-in for Communicator's barrier / max_over_ranks through files next to the
+    rendezvous path: what bench.py falls back to -- loudly, `config.exchange` says so -- when RCCL
+    cannot make a communicator, so that the ranks' timing protocol (barrier, K steps, barrier,
+    max over ranks) still holds.  It exchanges no detection records."""
+
+    def __init__(self, rank, world, path=None, timeout_s=300.0):
+        self.rank, self.world = int(rank), int(world)
+        self.base = (path or rendezvous_path()) + '.host'
+        self.timeout_s = timeout_s
+        self.n = 0
+
+    def _meet(self, payload):
+        self.n += 1
+        mine = '%s.%d.%d' % (self.base, self.n, self.rank)
+        tmp = mine + '.tmp'
+        with open(tmp, 'w') as fh:
+            fh.write(repr(float(payload)))
+        os.replace(tmp, mine)
+        vals, t0 = [], time.time()
+        for r in range(self.world):
+            f = '%s.%d.%d' % (self.base, self.n, r)
+            while not os.path.exists(f):
+                if time.time() - t0 > self.timeout_s:
+                    raise RuntimeError('rank %d: rank %d did not reach meeting %d' % (self.rank, r, self.n))
+                time.sleep(0.002)
+            vals.append(float(open(f).read()))
+        if self.n > 2:       # everyone has read meeting n - 2 by now (they wrote n - 1 and n after it)
+            try:
+                os.remove('%s.%d.%d' % (self.base, self.n - 2, self.rank))
+            except OSError:
+                pass
+        return vals
+
+    def barrier(self):
+        self._meet(0.0)
+
+    def max_over_ranks(self, value):
+        return max(self._meet(value))
+
+    def close(self):
+        """One last meeting, after which every rank has read everything up to the one before it: those
+        files go; the last meeting's own (a few bytes per rank) stay, a peer may still be reading them."""
+        self.barrier()
+        for k in (self.n - 2, self.n - 1):
+            try:
+                os.remove('%s.%d.%d' % (self.base, k, self.rank))
+            except OSError:
+                pass
+
+
 def rendezvous_path(env=None):
     """Where the ranks of one job meet: keyed by the launcher's rendezvous port and by the
     launcher's process id (the ranks of one node are children of one launcher -- torch.distributed.run's

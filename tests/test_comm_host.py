@@ -23,3 +23,27 @@ def test_comm_entry_points_reject_null_arguments():
     assert lib.dodt_comm_destroy(None) == _lib.OK
     with pytest.raises(ValueError):
         _lib.check(lib.dodt_comm_join(None, 0, None), 'join')
+
+
+def _host_rank(rank, world, path, q):
+    hb = sharding.HostBarrier(rank, world, path)
+    hb.barrier()
+    m = [hb.max_over_ranks(10.0 * k + rank) for k in range(5)]
+    hb.close()
+    q.put((rank, m))
+
+
+def test_host_barrier_fallback_two_processes(tmp_path):
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    path = str(tmp_path / 'rdzv')
+    procs = [ctx.Process(target=_host_rank, args=(r, 2, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [10.0 * k + 1 for k in range(5)]
+    assert len([f for f in os.listdir(str(tmp_path)) if f.startswith('rdzv.host')]) <= 2   # the last meeting's
