@@ -220,8 +220,11 @@ def main():
     from dodt_amd.pipeline import (CORR_CH, CORR_MAX_DISP, CORR_PAD, CORR_STRIDE2, MAX_DET, REC_COLS,
                                    ROI, FramePairPipeline)
     cfg = config.PYRAMID_DODT if args.config == 'dodt' else config.CARS_EXAMPLE
+    # DODT_BENCH_SAME_GPU=1 (rehearsal on a one-GPU box): every rank on device 0 -- RCCL refuses two
+    # ranks on one device, so this exercises the spawner, the rendezvous and the degraded mode
+    dev_id = 0 if os.environ.get('DODT_BENCH_SAME_GPU') == '1' else local_rank
     try:
-        ctx = device.Context(local_rank)
+        ctx = device.Context(dev_id)
     except _lib.DodtError as e:
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path (%s)' % e)
     comm, host_sync, comm_error = None, None, None
@@ -464,7 +467,7 @@ def main():
     m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype, detail=True)
     elapsed, host_enqueue_ms, conv_ms, reps = m['elapsed'], m['host_enqueue_ms'], m['conv_ms'], m['reps']
     alt = None
-    if not args.no_alt:
+    if not args.no_alt and world == 1:      # (N > 1 runs measure the sharded path only)
         # other arithmetics / batchings of the same workload, shorter runs: reported beside the
         # main measurement, never part of `value`
         k = max(5, args.steps // 2)

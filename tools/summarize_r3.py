@@ -154,6 +154,37 @@ if per:
             'dispatches': hbm_json['vox_scatter']['dispatches']}
     if hbm_json:
         json.dump({'kernels': hbm_json, 'source': src}, open(os.path.join(out, '%s_hbm_traffic.json' % tag), 'w'), indent=1)
+# the HBM-bound kernels on one page: bench.py's stand-alone timing + the counters of the same command
+if trace and bench and bench['roofline'].get('hbm') and per:
+    hl = ['# %s: HBM-bound kernels (north_star: "rocprof HBM GB/s for the voxeliser / ROI-crop")' % tag, '',
+          'Stand-alone section of the plain `bench.py` run (each kernel 20 x alone on the main stream, HIP events), the kernel',
+          'trace of the profiled run, and FETCH_SIZE x 2 / WRITE_SIZE of the separate `--pmc` passes (per launch).',
+          'Algorithmic bytes: SURVEY.md 8(d).  Peak 8000 GB/s.', '',
+          '| stage | kernel(s) | algorithmic MB | events us | trace us (kernels only) | GB/s (events) | of peak | fetch MB | write MB |',
+          '|---|---|---|---|---|---|---|---|---|']
+    plain = os.path.join(root, 'gpurun_out', '%s_bench.json' % tag)      # the un-profiled run's timing
+    hbm_rows = bench['roofline']['hbm']
+    if os.path.exists(plain):
+        pl = [l for l in open(plain) if l.startswith('{')]
+        if pl and json.loads(pl[-1])['roofline'].get('hbm'):
+            hbm_rows = json.loads(pl[-1])['roofline']['hbm']
+    for h in hbm_rows:
+        names = [n for n in HBM if n in h['kernel']]
+        tot = f_mb = w_mb = 0.0
+        for n in names:
+            sel = [r for r in tr if HBM[n] in r['Kernel_Name']][-20:]
+            tot += sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in sel) / 1e3 / max(len(sel), 1)
+            f_mb += per[n].get('fetch', [0, 1])[0] / max(per[n].get('fetch', [0, 1])[1], 1) / 1e6
+            w_mb += per[n].get('write', [0, 1])[0] / max(per[n].get('write', [0, 1])[1], 1) / 1e6
+        hl.append('| %s | %s | %.2f | %.2f | %.2f | %.0f | %.3f | %.2f | %.2f |' % (
+            h['stage'], h['kernel'], h['algorithmic_bytes'] / 1e6, h['us'], tot, h['gbps'], h['frac_of_hbm_peak'],
+            f_mb, w_mb))
+    hl += ['', 'Notes: the voxeliser is latency-bound at this size (469 workgroups of one wave round; its memset is '
+           'a separate 5 us fill kernel of the runtime: in the events column, but its 13.4 MB of writes are not a dispatch the counter pass lists); the '
+           'ROI crop reads mostly L2-resident taps (its counter traffic is half the algorithmic bound of SURVEY 8d, '
+           'which prices every tap); the correlation kernel moves 1.8 x its algorithmic bytes over the fabric (the '
+           'rows a tile shares with the tile below are fetched again), i.e. 5.8 TB/s of real traffic.']
+    open(os.path.join(out, '%s_hbm_summary.md' % tag), 'w').write('\n'.join(hl) + '\n')
 bj = os.path.join(root, 'gpurun_out', '%s_bench.json' % tag)
 if os.path.exists(bj):
     txt = [l for l in open(bj) if l.startswith('{')]
