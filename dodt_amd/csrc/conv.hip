@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <array>
+
 #include "common.h"
 #include "conv_kernels.h"
 #include "conv_variants.h"
@@ -839,9 +841,19 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
         // F(4x4,3x3) filter transform U = G g G^T (6x6 points; float64 on the host, rounded once),
         // blocked [n-tile][chunk][xi / 2][g = c / 2][cb][t][xi & 1][c & 1]: a lane (t, g) of channel
         // block cb reads 16 bytes = its channel pair for two points
-        static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6},
-                                       {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6},
-                                       {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+        // points 0, +-2/3, +-3/2, infinity (wino43_kernel.h): G[j][k] = p_j^k / prod_{l != j} (p_j - p_l)
+        static const std::array<std::array<double, 3>, 6> G = [] {
+            const double p[5] = {0.0, 2.0 / 3.0, -2.0 / 3.0, 1.5, -1.5};
+            std::array<std::array<double, 3>, 6> g{};
+            for (int j = 0; j < 5; ++j) {
+                double n = 1.0;
+                for (int l = 0; l < 5; ++l)
+                    if (l != j) n *= p[j] - p[l];
+                g[j] = {1.0 / n, p[j] / n, p[j] * p[j] / n};
+            }
+            g[5] = {0.0, 0.0, 1.0};
+            return g;
+        }();
         std::vector<float> u((size_t)36 * l.Cin * l.Cout, 0.0f);
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co) {

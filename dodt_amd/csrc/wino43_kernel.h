@@ -6,10 +6,11 @@
 // bound by MFMA cycles + transform cycles, and only fewer MFMAs per output make it faster.  F(4x4,
 // 3x3) computes a 4x4 block of outputs from a 6x6 block of inputs with 36 multiplications per
 // (input channel, output channel) instead of 144: 2.25 per output against 4 (F(2x2)) and 9 (direct).
-//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A      with the interpolation points 0, +-1, +-2, inf
-// fp32 throughout; the transforms use the constants 2, 4, 5, 8 (fused multiply-adds), the filter
-// transform (1/4, 1/6, 1/12, 1/24) runs on the host in float64.  Error against the direct form:
-// 3-5e-6 of a layer's scale (F(2x2): 2e-7; the per-layer bar of tests/test_gpu_conv.py is 1e-4).
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A      with the interpolation points 0, +-2/3, +-3/2, inf
+// fp32 throughout (fused multiply-adds in the transforms), the filter transform runs on the host in
+// float64.  Error against the direct form: ~1.5e-6 of a layer's scale (round 2's points 0, +-1, +-2:
+// 3-5e-6; F(2x2): 2e-7; the per-layer bar of tests/test_gpu_conv.py is 1e-4) -- which is why this
+// kernel is the OPT-IN fast form (DODT_CONV_WINO=4) and F(2x2,3x3) the default: DESIGN.md 5.0.
 //
 // Work decomposition (one workgroup = 4 waves, ONE per CU: 512 registers per lane):
 //   * workgroup tile 32 x 16 output pixels x 32 output channels; wave w: tile block w & 1 (16 x 16
@@ -23,7 +24,6 @@
 //     B^T d B (144 packed fused multiply-adds), then issues 72 MFMAs.
 //   * epilogue: A^T M A per lane (4 x 4 pixels x 4 channels), batch-norm + ReLU, 16-byte stores
 //     into the CB8 output; a lane's 4 x 4 outputs hold four windows of a following 2x2 max pool.
-// The last layer of a stack (NHWC output, fused 1x1 bottleneck) stays on the F(2x2) kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,7 +41,8 @@ struct Wino43Cfg {
     // LDS patch image: pixel (py, px) lives in 32-byte cell py * 34 + px + (py >> 2), its two
     // 16-byte halves swapped when (px >> 3) & 1: for every tap (r, c) of the 6x6 input tile the 16
     // lanes x 2 that one LDS cycle of a ds_read_b64 serves (4 x 4 tiles, pixels four apart) fall
-    // into 16 different 16-byte bank columns (found by search, tools/lds_swizzle_search.py).
+    // into 16 different 16-byte bank columns (tools/lds_swizzle_search.py reproduces the search and
+    // checks this and the other kernels' images).
     // Filled by LDS-DMA (lane-linear): the permutation is applied to the SOURCE address of a slot.
     static constexpr int kPitch = PW;
     static constexpr int kCells = (PH - 1) * kPitch + (PW - 1) + ((PH - 1) >> 2) + 1;   // 616
@@ -66,17 +67,34 @@ constexpr int tap_off_c(int r, int c) {
 __device__ __forceinline__ f32x2_t pk_fma(float k, f32x2_t a, f32x2_t b) {   // k * a + b
     return __builtin_elementwise_fma(f32x2_t{k, k}, a, b);
 }
+// Interpolation points of F(4,3): 0, +-a, +-b, infinity with a = 2/3, b = 3/2 (a b = 1).  Round 2 used
+// Lavin & Gray's 0, +-1, +-2, inf; what makes F(4x4,3x3) noisy in fp32 is the accumulation over the input
+// channels in the TRANSFORMED domain, whose values are larger than the outputs they cancel to, and that
+// amplification depends on the points: searched over symmetric sets (tests/experiments/wino_points.py),
+// the best lie at a ~ 0.65, b ~ 1.5 with 2.2x less rms error than (1, 2) -- the layer error against the
+// direct form falls from 4e-6 to 1.5e-6 of the scale (F(2x2,3x3): 2e-7), for two more packed operations
+// per 1-D transform.  With a b = 1:
+//     B^T = [ 1   0  -s   0   1   0 ]      s = a^2 + b^2 = 97/36         A^T = [ 1  1    1    1    1   0 ]
+//           [ 0  -b  -b2  a   1   0 ]      b2 = b^2 = 9/4                      [ 0  a   -a    b   -b   0 ]
+//           [ 0   b  -b2 -a   1   0 ]      a2 = a^2 = 4/9                      [ 0  a2   a2   b2   b2  0 ]
+//           [ 0  -a  -a2  b   1   0 ]                                          [ 0  a3  -a3   b3  -b3  1 ]
+//           [ 0   a  -a2 -b   1   0 ]
+//           [ 0   1   0  -s   0   1 ]      G[j][k] = p_j^k / prod_{l != j} (p_j - p_l), last row (0 0 1)
+// (the filter transform G g G^T runs on the host in float64: conv.hip; tests/test_wino_transforms.py checks
+// these matrices against the direct convolution).
+constexpr float kWa = 2.0f / 3.0f, kWb = 1.5f, kWa2 = 4.0f / 9.0f, kWb2 = 2.25f, kWs = 97.0f / 36.0f;
+constexpr float kWa3 = 8.0f / 27.0f, kWb3 = 3.375f;
 // B^T of F(4,3) applied to six values in place
 __device__ __forceinline__ void wino43_bt(f32x2_t& x0, f32x2_t& x1, f32x2_t& x2, f32x2_t& x3, f32x2_t& x4,
                                           f32x2_t& x5) {
-    const f32x2_t a = pk_fma(-4.f, x2, x4), b = pk_fma(-4.f, x1, x3);
-    const f32x2_t c = x4 - x2, e = x3 - x1;
-    const f32x2_t y0 = pk_fma(4.f, x0, pk_fma(-5.f, x2, x4));
-    const f32x2_t y5 = pk_fma(4.f, x1, pk_fma(-5.f, x3, x5));
-    x1 = a + b;
-    x2 = a - b;
-    x3 = pk_fma(2.f, e, c);
-    x4 = pk_fma(-2.f, e, c);
+    const f32x2_t e1 = pk_fma(-kWb2, x2, x4), e2 = pk_fma(-kWa2, x2, x4);
+    const f32x2_t o1 = pk_fma(-kWb, x1, f32x2_t{kWa, kWa} * x3), o2 = pk_fma(-kWa, x1, f32x2_t{kWb, kWb} * x3);
+    const f32x2_t y0 = x0 + pk_fma(-kWs, x2, x4);
+    const f32x2_t y5 = x1 + pk_fma(-kWs, x3, x5);
+    x1 = e1 + o1;
+    x2 = e1 - o1;
+    x3 = e2 + o2;
+    x4 = e2 - o2;
     x0 = y0;
     x5 = y5;
 }
@@ -89,9 +107,9 @@ __device__ __forceinline__ void wino43_at(const f32x4& m0, const f32x4& m1, cons
                                           f32x4& o3) {
     const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     o0 = (m0 + s1) + s2;
-    o1 = v4_fma(2.f, d2, d1);
-    o2 = v4_fma(4.f, s2, s1);
-    o3 = v4_fma(8.f, d2, d1) + m5;
+    o1 = v4_fma(kWb, d2, f32x4{kWa, kWa, kWa, kWa} * d1);
+    o2 = v4_fma(kWb2, s2, f32x4{kWa2, kWa2, kWa2, kWa2} * s1);
+    o3 = v4_fma(kWb3, d2, f32x4{kWa3, kWa3, kWa3, kWa3} * d1) + m5;
 }
 
 // The accumulators live in AGPRs and every MFMA accumulates in place (vDst = SrcC), written as
