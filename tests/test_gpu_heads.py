@@ -180,7 +180,7 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
             rows = b['corr_rois'].download()[:n_top]        # rows padded to the head's K (zeros)
             assert rows.shape[1] == pipe.corr_head.in_ld and not rows[:, 7 * 7 * CORR_CH:].any()
             got_rois = rows[:, :7 * 7 * CORR_CH].reshape(n_top, 7, 7, CORR_CH)
-            _close(got_rois, want_rois, 5e-4)
+            _close(got_rois, want_rois, 2e-5)      # the oracle correlates the DEVICE's feature maps
             heads['corr_offsets'] = b['corr_offsets'].download()[:n_top]
             _close(heads['corr_offsets'], oheads.corr_fc_early(got_rois, hp['corr'], head_dtype), tol)
         # everything downstream of the heads, exact on indices
@@ -329,7 +329,7 @@ def test_pair_free_running_by_conv_mode(tmp_path):
             row[base] = [agreement(got['top%d' % f], got['rec%d' % f], oracle[base][1][f])
                          for f in range(2)]
         # error of the stack's output and of the 7x7 crops taken from it, against both oracles'
-        # feature maps (of the map's scale): the crop bar of tests/test_gpu_pipeline.py is 5e-4
+        # feature maps (of the map's scale): the fp32 crop bar of tests/test_gpu_pipeline.py is 1e-5
         for base in ('f32', 'exact'):
             ferr, cerr = [], []
             for f in range(2):

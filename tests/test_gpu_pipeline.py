@@ -75,11 +75,14 @@ def test_frame_pair_matches_oracle(setup, conv_dtype):
         if f == 0:
             for name in ('rpn_bev_roi', 'rpn_img_roi', 'bev_rois', 'img_rois'):
                 got = b[name].download()[:len(want[name])]
-                # crops of 16-layer fp32 feature maps: the GPU sums each conv output as
-                # one fmaf chain, the oracle as nine partial GEMMs; the two float32
-                # results drift apart by a few 1e-4 of the map's scale
+                # crops of 16-layer feature maps: device and oracle sum every conv output in
+                # different float32 orders.  Measured per form of the fp32 3x3 layers
+                # (tests/test_gpu_heads.py::test_pair_free_running_by_conv_mode prints them):
+                # direct 5.4e-7, Winograd F(2x2,3x3) (the default) 4.5e-7, F(4x4,3x3) 8.5e-7 of the
+                # map's scale; the split mode on the bf16 MFMA (hi + lo bf16 operands) ~5e-5.
                 scale = np.abs(want[name]).max() + 1e-12
-                assert np.abs(got - want[name]).max() <= 5e-4 * scale, name
+                bar = 1e-5 if conv_dtype == 'f32' else 5e-4
+                assert np.abs(got - want[name]).max() <= bar * scale, (name, np.abs(got - want[name]).max() / scale)
 
 
 def test_two_pairs_per_step_match_single_pair_steps(setup):
@@ -226,7 +229,7 @@ def test_single_frame_cars_example_matches_oracle():
     for name in ('rpn_bev_roi', 'rpn_img_roi', 'bev_rois', 'img_rois'):
         got = b[name].download()[:len(want[name])]
         scale = np.abs(want[name]).max() + 1e-12
-        assert np.abs(got - want[name]).max() <= 5e-4 * scale, name
+        assert np.abs(got - want[name]).max() <= 1e-5 * scale, (name, np.abs(got - want[name]).max() / scale)
     pipe.close()
 
 
