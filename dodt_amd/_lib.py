@@ -119,6 +119,7 @@ SIGNATURES = {
     'dodt_crop_and_resize_strided': (_i, [_vp, _pf, _i, _i, _i, _pf, _i, _pi32, _i, _i, _pf,
                                           C.c_longlong]),
     'dodt_correlation': (_i, [_vp, _pf, _pf, _i, _i, _i, _i, _i, _i, _pf]),
+    'dodt_mean_fusion': (_i, [_vp, _pf, _pf, _i, _pi32, _i, _pf]),
     'dodt_fc_create': (_i, [_vp, _i, _i, _hf, _hf, _i, C.POINTER(_vp)]),
     'dodt_fc_create_ex': (_i, [_vp, _i, _i, _hf, _hf, _i, C.POINTER(_vp)]),
     'dodt_fc_destroy': (_i, [_vp]),

@@ -37,14 +37,21 @@ class EarlyFusionFcLayers(object):
         self.ctx = ctx
 
     def make_scratch(self, n_max):
-        """Ping-pong hidden activations; one set per concurrent stream."""
-        return [self.ctx.empty((n_max, self.width), np.float32) for _ in range(2)]
+        """Ping-pong hidden activations + the fused input rows; one set per concurrent stream."""
+        return [self.ctx.empty((n_max, self.width), np.float32) for _ in range(2)] + \
+               [self.ctx.zeros((n_max, self.in_ld), np.float32)]
 
     def forward(self, ctx, d_rois, d_rois2, n, d_n, d_outs, scratch):
         """d_rois: n rows of `in_ld` floats, the flattened (h,w,c) crop in front and zeros behind it
         (= (n,h,w,c) when in_ld == h*w*c) [and d_rois2, fused by mean]; *d_n rows are valid;
         d_outs: one (n, size) array per output layer."""
         x, x2, ldx = d_rois, d_rois2, self.in_ld
+        if x2 is not None and len(scratch) > 2 and self.in_ld == self.in_k and self.in_k % 4 == 0:
+            # the mean of the two crops as its own pass (avod_fc_layer_utils.py:38-41: (a + b) / 2,
+            # the same float32 arithmetic): fc6 then runs as the plain GEMM, twice as fast as the
+            # form that averages inside its K loop
+            ops.mean_fusion(ctx, x, x2, n, d_n, self.in_ld, scratch[2])
+            x, x2 = scratch[2], None
         for i, l in enumerate(self.hidden):
             y = scratch[i & 1]
             l.forward(x, n, y, ldx=ldx, ldy=self.width, d_x2=x2, d_m=d_n, ctx=ctx)

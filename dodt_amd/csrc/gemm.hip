@@ -26,6 +26,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <algorithm>
+
 #include "common.h"
 #include "lds_dma.h"
 
@@ -493,6 +495,38 @@ int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
 }
 
 }  // namespace
+
+// (a + b) / 2 of two row-major blocks, rows limited by *d_n: the heads' "mean" fusion of BEV and image
+// crops as its own pass (6.4 MB each at 1024 x 7 x 7 x 32), so that the GEMM behind it is the plain one
+namespace {
+__global__ void __launch_bounds__(256)
+mean_fusion_kernel(const float4* __restrict__ a, const float4* __restrict__ b, int rows, const int* __restrict__ d_n,
+                   int row4, float4* __restrict__ out) {
+    const int lim = d_n ? min(*d_n, rows) : rows;
+    const long long total = (long long)lim * row4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = a[i], y = b[i];
+        out[i] = make_float4((x.x + y.x) / 2.0f, (x.y + y.y) / 2.0f, (x.z + y.z) / 2.0f, (x.w + y.w) / 2.0f);
+    }
+}
+}  // namespace
+
+extern "C" int dodt_mean_fusion(dodt_ctx* ctx, const float* d_a, const float* d_b, int rows, const int32_t* d_n,
+                                int row_floats, float* d_out) {
+    DODT_REQUIRE(ctx && d_a && d_b && d_out, "dodt_mean_fusion: NULL argument");
+    DODT_REQUIRE(rows >= 0 && row_floats >= 4 && row_floats % 4 == 0,
+                 "dodt_mean_fusion: rows of a multiple of four floats, got %d", row_floats);
+    DODT_REQUIRE(((size_t)d_a | (size_t)d_b | (size_t)d_out) % 16 == 0, "dodt_mean_fusion: 16-byte aligned blocks");
+    if (rows == 0) return DODT_OK;
+    const long long total = (long long)rows * (row_floats / 4);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(mean_fusion_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float4*>(d_a), reinterpret_cast<const float4*>(d_b), rows, d_n,
+                       row_floats / 4, reinterpret_cast<float4*>(d_out));
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
 
 struct dodt_fc {
     dodt_ctx* ctx = nullptr;

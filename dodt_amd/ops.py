@@ -181,6 +181,12 @@ def correlation(ctx, d_a, d_b, hwc, max_displacement, stride_2, pad, d_out):
         int(max_displacement), int(stride_2), int(pad), _p(d_out)), 'dodt_correlation')
 
 
+def mean_fusion(ctx, d_a, d_b, rows, d_n, row_floats, d_out):
+    """d_out = (d_a + d_b) / 2 over min(*d_n, rows) rows of row_floats floats."""
+    _lib.check(ctx.lib.dodt_mean_fusion(ctx.handle, _p(d_a), _p(d_b), int(rows), _p(d_n),
+                                        int(row_floats), _p(d_out)), 'dodt_mean_fusion')
+
+
 class FullyConnected(object):
     """y = act(x w + b) on the device (dodt_fc_*).  w (K,N) row-major, the layout of the
     TF variable (conv kernels reshaped (kh*kw*cin, cout))."""

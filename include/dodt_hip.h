@@ -317,6 +317,13 @@ int dodt_correlation(dodt_ctx* ctx, const float* d_a, const float* d_b, int H, i
  * cout)); relu != 0 applies ReLU.  d_x2 (may be NULL): x = (x + x2) / 2, the "mean" fusion
  * of BEV and image crops.  ldx, ldy: row strides in floats; *d_m (may be NULL) overrides M
  * on the device.  ctx == NULL in forward uses the creating context's stream. */
+/* d_out[r][k] = (d_a[r][k] + d_b[r][k]) / 2 for r < min(*d_n, rows): the "mean" fusion of the BEV and
+ * image crops (avod/core/avod_fc_layers/avod_fc_layer_utils.py:38-41, dt_rpn_model.py:434-439 with
+ * both path-drop masks 1) as a pass of its own, in front of a layer that then runs without d_x2 (the
+ * GEMM with the fusion inside its K loop is half as fast at the stage-2 head's size).  row_floats a
+ * multiple of 4, blocks 16-byte aligned and contiguous. */
+int dodt_mean_fusion(dodt_ctx* ctx, const float* d_a, const float* d_b, int rows, const int32_t* d_n,
+                     int row_floats, float* d_out);
 typedef struct dodt_fc dodt_fc;
 int dodt_fc_create(dodt_ctx* ctx, int K, int N, const float* w, const float* bias, int relu,
                    dodt_fc** out);
