@@ -58,6 +58,11 @@ __device__ __forceinline__ void cmp_swap(unsigned long long& a, unsigned long lo
 }
 
 // Sorts each kTile-key tile completely (all bitonic stages with k <= tile size).
+// (Round 3 rebuilt this with eight keys per thread in registers, wave shuffles for the strides inside a
+//  wave and LDS only for strides >= 512 -- 10 barrier steps instead of 91: the same 55-60 us for an
+//  8192-key tile.  What bounds a one-workgroup bitonic sort is the 370k 64-bit compare-exchanges on one
+//  CU's vector ALUs, not the barriers; a faster NMS #1 needs fewer keys (select the top ~2k by a
+//  histogram of the score bits first) or many CUs, not a leaner network.  tools/nms_bench.py times it.)
 __global__ void __launch_bounds__(kSortThreads)
 nms_sort_local(unsigned long long* __restrict__ keys, int n_pad) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];

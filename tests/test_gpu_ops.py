@@ -221,3 +221,41 @@ def test_angle_vector_to_orientation(ctx):
     assert len(gpu_orient.tf_angle_vector_to_orientation(np.zeros((0, 2)), ctx=ctx)) == 0
     with pytest.raises(ValueError):
         gpu_orient.tf_angle_vector_to_orientation(np.zeros((4, 3)), ctx=ctx)
+
+
+@pytest.mark.parametrize('hwc,crop,stride', [((30, 40, 25), (7, 7), 1248), ((44, 50, 32), (7, 7), 1600),
+                                             ((20, 20, 3), (2, 2), 13)])
+def test_strided_crop_rows_are_the_packed_crops(ctx, hwc, crop, stride):
+    """dodt_crop_and_resize_strided: box b's crop at b * stride floats, the floats between crops untouched
+    (the correlation head's rows of 1248 = 7*7*25 + 23 zeros; also a stride that is no multiple of 4)."""
+    rng = np.random.default_rng(stride)
+    img = rng.normal(size=hwc).astype(np.float32)
+    b = _boxes(rng, 200)
+    n = crop[0] * crop[1] * hwc[2]
+    d_out = ctx.array(np.full((200, stride), 7.5, np.float32))
+    d_n = ctx.array(np.array([150], np.int32))
+    ops.crop_and_resize(ctx, ctx.array(img), hwc, ctx.array(b), 200, d_n, crop, d_out, out_box_stride=stride)
+    got = d_out.download()
+    want = tfops.crop_and_resize(img, b[:150], crop[0], crop[1]).reshape(150, n)
+    assert np.array_equal(got[:150, :n], want)
+    assert np.all(got[:150, n:] == 7.5) and np.all(got[150:] == 7.5)
+    with pytest.raises(ValueError):
+        ops.crop_and_resize(ctx, ctx.array(img), hwc, ctx.array(b), 200, None, crop, d_out, out_box_stride=n - 1)
+
+
+def test_mean_fusion_is_the_float32_mean(ctx):
+    """dodt_mean_fusion: (a + b) / 2 in float32, exactly, over min(*d_n, rows) rows
+    (avod_fc_layer_utils.py:38-41 with both path-drop masks 1)."""
+    from oracle import heads as oheads
+    rng = np.random.default_rng(77)
+    a = (rng.normal(size=(333, 1568)) * 10.0 ** rng.integers(-20, 20, size=(333, 1))).astype(np.float32)
+    b = rng.normal(size=(333, 1568)).astype(np.float32)
+    d_out = ctx.array(np.full((333, 1568), -3.0, np.float32))
+    ops.mean_fusion(ctx, ctx.array(a), ctx.array(b), 333, ctx.array(np.array([300], np.int32)), 1568, d_out)
+    got = d_out.download()
+    assert np.array_equal(got[:300], oheads.mean_fusion(a[:300], b[:300]))
+    assert np.all(got[300:] == -3.0)
+    ops.mean_fusion(ctx, ctx.array(a), ctx.array(b), 333, None, 1568, d_out)
+    assert np.array_equal(d_out.download(), oheads.mean_fusion(a, b))
+    with pytest.raises(ValueError):
+        ops.mean_fusion(ctx, ctx.array(a), ctx.array(b), 333, None, 1567, d_out)
