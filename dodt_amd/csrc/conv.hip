@@ -124,13 +124,15 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     // fp32 transposed convs: the LDS-DMA staged kernel (deconv_kernel.h; DODT_CONV_DECONV_DMA=0: the
     // register-staged direct kernel's deconv instantiation)
     static const bool deconv_dma = !(getenv("DODT_CONV_DECONV_DMA") && atoi(getenv("DODT_CONV_DECONV_DMA")) == 0);
-    if (deconv_dma && deconv && !bf16 && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
+    // (bf16 transposed convs take the same kernel on the bf16 MFMA since round 3; DODT_CONV_DECONV_DMA=0
+    //  puts both back on the register-staged template)
+    if (deconv_dma && deconv && parts == 1 && Cin >= 32 && Cin % 16 == 0) {
         // 32-channel tiles unless that leaves fewer than four items per CU (the CUs are MFMA-bound:
         // what counts is how evenly the items spread)
         const int n32 = dodt::ceil_div(H, 16) * dodt::ceil_div(W, 16) * (Cout / 32) * batch;
         const int want_bn = (Cout % 32 == 0 && n32 >= 4 * num_cus) ? 32 : 16;
         for (size_t i = 0; i < vs.size(); ++i)
-            if (vs[i].deconv_dma && vs[i].BN == want_bn && Cout % want_bn == 0) return (int)i;
+            if (vs[i].deconv_dma && vs[i].bf16 == bf16 && vs[i].BN == want_bn && Cout % want_bn == 0) return (int)i;
     }
     // bf16 3x3 stride-1 layers: the LDS-DMA staged kernel (conv_bf16_dma.h: scalar-only copy issue
     // between the MFMAs, accumulators pinned in place; stacks alone as fast as the template's bf16
@@ -504,7 +506,7 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
 // the __global__ function a variant launches (what rocprofv3 --kernel-trace lists)
 const char* kernel_name(const KernelVariant& v) {
     if (v.wino) return v.wino_m == 4 ? "wino43_f32_kernel" : "wino3x3_f32_kernel";
-    if (v.deconv_dma) return "deconv3x3_f32_kernel";
+    if (v.deconv_dma) return "deconv3x3_dma_kernel";
     if (v.dma) return "conv3x3_bf16_dma_kernel";
     if (v.small_cin) return "conv3x3_small_cin_kernel";
     return "conv3x3_mfma_kernel";
@@ -819,17 +821,25 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
     if (v.deconv_dma) {
         // transposed conv, TF layout (kh, kw, Cout, Cin): blocked [n-tile][chunk][tap][g = c / 2][t]
         // [channel block][c & 1]: a lane (t, g) reads 16 bytes = its channel pair for both blocks
+        // (bf16: the same bytes hold 16 channels per chunk, [g = c / 4] ... [c & 3] as bf16)
         const int ncb = v.BN / 16;
         const size_t chunk_floats = (size_t)(9 * 8 * v.BN + 255) / 256 * 256;     // whole 1 KB pieces
         std::vector<float> u((size_t)(l.Cout / v.BN) * nchunks * chunk_floats, 0.0f);
+        uint16_t* u16 = reinterpret_cast<uint16_t*>(u.data());
         for (int tap = 0; tap < 9; ++tap)
             for (int ci = 0; ci < cin; ++ci)
                 for (int co = 0; co < cout; ++co) {
-                    const int nt = co / v.BN, n = co % v.BN, ch = ci / 8, c = ci % 8;
-                    const int cb = n / 16, t = n % 16;
-                    u[((size_t)nt * nchunks + ch) * chunk_floats +
-                      ((((size_t)tap * 4 + c / 2) * 16 + t) * ncb + cb) * 2 + (c & 1)] =
-                        w[((size_t)tap * cout + co) * cin + ci];
+                    const float val = w[((size_t)tap * cout + co) * cin + ci];
+                    const int nt = co / v.BN, n = co % v.BN, cb = n / 16, t = n % 16;
+                    if (v.bf16) {
+                        const int ch = ci / 16, c = ci % 16;
+                        u16[(((size_t)nt * nchunks + ch) * chunk_floats) * 2 +
+                            ((((size_t)tap * 4 + c / 4) * 16 + t) * ncb + cb) * 4 + (c & 3)] = dodt::float_to_bf16(val);
+                    } else {
+                        const int ch = ci / 8, c = ci % 8;
+                        u[((size_t)nt * nchunks + ch) * chunk_floats +
+                          ((((size_t)tap * 4 + c / 2) * 16 + t) * ncb + cb) * 2 + (c & 1)] = val;
+                    }
                 }
         if (!ln->d_w) DODT_HIP_CHECK(hipMalloc(&ln->d_w, u.size() * sizeof(float)));
         DODT_HIP_CHECK(hipMemcpyAsync(ln->d_w, u.data(), u.size() * sizeof(float),

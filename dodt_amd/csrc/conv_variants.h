@@ -96,20 +96,21 @@ struct InstWino43 {
     }
 };
 
-template <int CB>
+template <int CB, bool BF16 = false>
 struct InstDeconvDma {
     using Cfg = DeconvCfg<CB>;
     static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL(deconv3x3_f32_kernel<CB>, grid, dim3(256), Cfg::kLdsBytes, s, a);
+        hipLaunchKernelGGL((deconv3x3_dma_kernel<CB, BF16>), grid, dim3(256), Cfg::kLdsBytes, s, a);
     }
     static hipError_t prepare() {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3_f32_kernel<CB>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3_dma_kernel<CB, BF16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
     }
     static KernelVariant variant() {
-        KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, kCK, true, false, Cfg::TH, Cfg::kLdsBytes, 2,
+        KernelVariant v{Cfg::TW, 0, 4, 1, Cfg::BN, BF16 ? 16 : kCK, true, false, Cfg::TH, Cfg::kLdsBytes, 2,
                         &launch, &prepare};
         v.deconv_dma = true;
+        v.bf16 = BF16;
         return v;
     }
 };

@@ -1,5 +1,9 @@
-// 3x3 stride-2 transposed convolution (slim.conv2d_transpose, SAME: output 2H x 2W) in fp32 on the
-// fp32 MFMA of gfx950, LDS-DMA staged -- the upconv layers of the pyramid extractors.
+// 3x3 stride-2 transposed convolution (slim.conv2d_transpose, SAME: output 2H x 2W) on the MFMA of
+// gfx950, LDS-DMA staged -- the upconv layers of the pyramid extractors.  fp32 (v_mfma_f32_16x16x4_f32,
+// CB8 maps) and, since round 3, the bf16 conv path (BF16: v_mfma_f32_16x16x16_bf16 on CB16 bf16 maps).
+// The two are byte-identical in everything but the MFMA: a CB16 bf16 pixel is 32 bytes like a CB8 fp32
+// one, a lane's 8-byte LDS read holds input channels 4g .. 4g+3 as bf16 where it held 2g, 2g+1 as
+// floats, and ONE 16x16x16 MFMA takes the 16 channels of a chunk that two 16x16x4 ones take 8 of.
 //
 // out[2i + ky - 2 di][2j + kx - 2 dj] += in[i - di][j - dj] . w[ky][kx]: every tap feeds one
 // output-parity class from one of the four input pixels (i, j), (i-1, j), (i, j-1), (i-1, j-1);
@@ -57,10 +61,19 @@ struct DeconvTap { int tap, cls, di, dj; };
 constexpr DeconvTap kDeconvTaps[9] = {{0, 0, 0, 0}, {1, 1, 0, 0}, {3, 2, 0, 0}, {4, 3, 0, 0}, {6, 0, 1, 0},
                                       {7, 1, 1, 0}, {5, 2, 0, 1}, {2, 0, 0, 1}, {8, 0, 1, 1}};
 
-template <int CB>
+// bf16 twins of mfma43_acc / mfma43_first: operands are register pairs holding four bf16 each
+__device__ __forceinline__ void mfma_bf16x4_acc(f32x2_t w, f32x2_t v, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(v));
+}
+__device__ __forceinline__ void mfma_bf16x4_first(f32x2_t w, f32x2_t v, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(v));
+}
+
+template <int CB, bool BF16>
 __global__ void __launch_bounds__(256, 2)
-deconv3x3_f32_kernel(const ConvArgs a) {
+deconv3x3_dma_kernel(const ConvArgs a) {
     using Cfg = DeconvCfg<CB>;
+    constexpr int kChunkCh = BF16 ? 16 : 8;        // input channels per chunk = per 32-byte pixel cell
     constexpr int BN = Cfg::BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* s_ctrl = reinterpret_cast<int*>(smem + 2 * Cfg::kBufFloats);
@@ -69,8 +82,8 @@ deconv3x3_f32_kernel(const ConvArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = lane & 15, g = lane >> 4;
-    const int nchunks = a.Cin / 8;
-    const int in_plane = a.H * a.W * 8;
+    const int nchunks = a.Cin / kChunkCh;
+    const int in_plane = a.H * a.W * 8;          // floats per plane (32 bytes per pixel either way)
     const int plane_bytes = in_plane * 4;
 
     struct Item { int frame, ntile, ty0, tx0; };
@@ -94,7 +107,7 @@ deconv3x3_f32_kernel(const ConvArgs a) {
             p_off[k] = ok ? ((gy * a.W + gx) * 8 + hf * 4) * 4 : kOob;
         }
         const float* in_item = a.in + (size_t)it.frame * a.in_frame_stride +
-                               (size_t)(a.in_coff / 8) * in_plane;
+                               (size_t)(a.in_coff / kChunkCh) * in_plane;
         in_rsrc = make_rsrc(in_item, (unsigned)(nchunks * plane_bytes));
     };
     auto setup_w = [&](const Item& it) {
@@ -200,9 +213,15 @@ deconv3x3_f32_kernel(const ConvArgs a) {
                 const f32x2_t x = xin[r + 1 - di][dj];
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    if (FIRST && s < 4) mfma43_first(w[cb * 2 + 0], x[0], acc[r][cls][cb]);
-                    else mfma43_acc(w[cb * 2 + 0], x[0], acc[r][cls][cb]);
-                    mfma43_acc(w[cb * 2 + 1], x[1], acc[r][cls][cb]);
+                    if constexpr (BF16) {
+                        const f32x2_t wv = {w[cb * 2 + 0], w[cb * 2 + 1]};       // four bf16: channels 4g .. 4g+3
+                        if (FIRST && s < 4) mfma_bf16x4_first(wv, x, acc[r][cls][cb]);
+                        else mfma_bf16x4_acc(wv, x, acc[r][cls][cb]);
+                    } else {
+                        if (FIRST && s < 4) mfma43_first(w[cb * 2 + 0], x[0], acc[r][cls][cb]);
+                        else mfma43_acc(w[cb * 2 + 0], x[0], acc[r][cls][cb]);
+                        mfma43_acc(w[cb * 2 + 1], x[1], acc[r][cls][cb]);
+                    }
                 }
             }
             if (s < kCopies) copy_n(s, PAR ^ 1);     // scalar + VMEM issue in the MFMAs' shadow
@@ -243,7 +262,10 @@ deconv3x3_f32_kernel(const ConvArgs a) {
                 const int c0 = it.ntile * BN + cb * 16 + 4 * g;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
-                float* obase = out + (size_t)((a.out_coff + c0) >> 3) * plane + ((a.out_coff + c0) & 7);
+                // CB8 fp32: plane (channel >> 3), float (channel & 7) of the pixel's 8; CB16 bf16: plane
+                // (channel >> 4), the lane's four channels are floats ((channel & 15) >> 1) .. + 1
+                float* obase = BF16 ? out + (size_t)((a.out_coff + c0) >> 4) * plane + (((a.out_coff + c0) & 15) >> 1)
+                                    : out + (size_t)((a.out_coff + c0) >> 3) * plane + ((a.out_coff + c0) & 7);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int y = it.ty0 + 4 * wave + r;
@@ -256,9 +278,13 @@ deconv3x3_f32_kernel(const ConvArgs a) {
                             const float tv = v[k] * sc[k] + sh[k];
                             v[k] = a.relu ? fmaxf(tv, 0.0f) : tv;
                         }
-                        if (ok)
-                            *reinterpret_cast<f32x4*>(obase + ((size_t)(2 * y + (cls >> 1)) * (2 * a.W) +
-                                                               2 * x + (cls & 1)) * 8) = v;
+                        float* dst = obase + ((size_t)(2 * y + (cls >> 1)) * (2 * a.W) + 2 * x + (cls & 1)) * 8;
+                        if (ok) {
+                            if constexpr (BF16)     // round to nearest even, as every map of the bf16 path
+                                *reinterpret_cast<f32x2_t*>(dst) = f32x2_t{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                            else
+                                *reinterpret_cast<f32x4*>(dst) = v;
+                        }
                     }
                 }
             }

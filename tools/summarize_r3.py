@@ -14,7 +14,7 @@ import os
 import shutil
 import sys
 
-CONV = ('wino43_f32_kernel', 'wino3x3_f32_kernel', 'deconv3x3_f32_kernel', 'conv3x3_bf16_dma_kernel',
+CONV = ('wino43_f32_kernel', 'wino3x3_f32_kernel', 'deconv3x3_dma_kernel', 'deconv3x3_f32_kernel', 'conv3x3_bf16_dma_kernel',
         'conv3x3_small_cin_kernel', 'conv3x3_mfma_kernel')
 HBM = {'crop_kernel<4>': 'crop_kernel<4>', 'correlation_kernel': 'correlation_kernel',
        'vox_scatter': 'vox_scatter', 'vox_finalize': 'vox_finalize'}
