@@ -104,8 +104,8 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
     // fp32 3x3 stride-1 convs with >= 4 chunks of input channels run as Winograd.
     // dodt_conv_mode(): 2 (default) = F(2x2,3x3) with 128 accumulators, two workgroups per CU
     // (wino_kernels.h: both stacks 3.0 ms, rounding noise at the direct kernels' level), 4 =
-    // F(4x4,3x3) (wino43_kernel.h: 2.7 ms, but its fp32 accumulation in the transformed domain is
-    // 20x noisier, which halves the end-to-end agreement with the exact result: opt-in), 1 = the
+    // F(4x4,3x3) (wino43_kernel.h: 2.8 ms, but its fp32 accumulation in the transformed domain is
+    // 7x noisier, which costs a third of the end-to-end agreement with the exact result: opt-in), 1 = the
     // 256-accumulator F(2x2) variants, one workgroup per CU (no faster than direct), 0 = the direct
     // kernels (4.8 ms).
     static const int wino_mode = dodt_conv_mode();

@@ -130,7 +130,7 @@ def test_other_fp32_conv_paths_match_oracle(mode):
     in a child process (the library reads DODT_CONV_WINO once per process): the direct implicit-GEMM
     kernels (0), Winograd F(2x2,3x3) with 128 accumulators (2: the default, what every other test
     in this file runs) and its 256-accumulator variants (1), Winograd F(4x4,3x3) (4: the fastest;
-    3-5e-6 of a layer's scale from the oracle where the others are at 2e-7, which is why it is not
+    1.5e-6 of a layer's scale from the oracle where the others are at 2e-7, which is why it is not
     the default -- tests/test_gpu_heads.py::test_pair_free_running_by_conv_mode)."""
     import os
     import subprocess
