@@ -68,3 +68,60 @@ def test_fc_and_softmax_match_torch():
     _close(oheads.fc(x, w, b, True), want)
     logits = rng.normal(size=(50, 2)).astype(np.float32)
     _close(tfops.softmax2(logits), F.softmax(torch.tensor(logits), 1).numpy(), 1e-6)
+
+
+def test_crop_and_resize_matches_torch_grid_sample_inside_the_image():
+    """tf.image.crop_and_resize samples at in_y = y1 (H-1) + iy (y2-y1)(H-1)/(ch-1): the corner-aligned
+    bilinear grid, which is torch's grid_sample(align_corners=True) on the normalised coordinates
+    2 in / (size-1) - 1.  (The two differ only in how they extrapolate: TF zeroes a sample whose centre
+    lies outside the image, torch blends with zeros; boxes here stay inside.)"""
+    rng = np.random.default_rng(11)
+    h, w, c, n, ch, cw = 23, 31, 5, 40, 7, 7
+    img = rng.normal(size=(h, w, c)).astype(np.float32)
+    y1, x1 = rng.uniform(0, 0.6, n), rng.uniform(0, 0.6, n)
+    boxes = np.stack([y1, x1, y1 + rng.uniform(0.05, 0.39, n), x1 + rng.uniform(0.05, 0.39, n)], 1).astype(np.float32)
+    boxes[0] = [0, 0, 1, 1]
+    got = tfops.crop_and_resize(img, boxes, ch, cw)
+    iy = np.arange(ch) / (ch - 1)
+    ix = np.arange(cw) / (cw - 1)
+    gy = 2 * (boxes[:, None, 0] + iy[None] * (boxes[:, 2] - boxes[:, 0])[:, None]) - 1        # (n, ch)
+    gx = 2 * (boxes[:, None, 1] + ix[None] * (boxes[:, 3] - boxes[:, 1])[:, None]) - 1        # (n, cw)
+    grid = np.stack([np.broadcast_to(gx[:, None, :], (n, ch, cw)), np.broadcast_to(gy[:, :, None], (n, ch, cw))], -1)
+    t = torch.tensor(img).permute(2, 0, 1)[None].expand(n, -1, -1, -1)
+    want = F.grid_sample(t, torch.tensor(grid, dtype=torch.float32), mode='bilinear', padding_mode='zeros',
+                         align_corners=True).permute(0, 2, 3, 1).numpy()
+    _close(got, want, 2e-5)
+
+
+def test_nms_matches_a_quadratic_restatement():
+    """tf.image.non_max_suppression as three nested python facts -- sort by score, keep a box unless an
+    earlier kept one overlaps it by more than the threshold, stop at max_output -- against the oracle's
+    vectorised form, incl. corner order normalisation and the zero-area rule of TF's IoU."""
+    rng = np.random.default_rng(12)
+    n = 400
+    c = rng.uniform(0, 1, size=(n, 2))
+    hw = rng.uniform(0.0, 0.15, size=(n, 2))
+    boxes = np.concatenate([c - hw, c + hw], 1).astype(np.float32)
+    boxes[::7] = boxes[::7][:, [2, 3, 0, 1]]              # flipped corners
+    boxes[5] = [0.3, 0.3, 0.3, 0.5]                        # zero area
+    scores = rng.uniform(size=n).astype(np.float32)
+
+    def iou(a, b):
+        ay0, ay1, ax0, ax1 = min(a[0], a[2]), max(a[0], a[2]), min(a[1], a[3]), max(a[1], a[3])
+        by0, by1, bx0, bx1 = min(b[0], b[2]), max(b[0], b[2]), min(b[1], b[3]), max(b[1], b[3])
+        aa, ab = np.float32(ay1 - ay0) * np.float32(ax1 - ax0), np.float32(by1 - by0) * np.float32(bx1 - bx0)
+        if aa <= 0 or ab <= 0:
+            return np.float32(0)
+        ih = max(np.float32(0), np.float32(min(ay1, by1) - max(ay0, by0)))
+        iw = max(np.float32(0), np.float32(min(ax1, bx1) - max(ax0, bx0)))
+        inter = np.float32(ih * iw)
+        return np.float32(inter / np.float32(np.float32(aa + ab) - inter))
+    for thr, k in ((0.5, 60), (0.01, 400), (0.8, 100)):
+        order = sorted(range(n), key=lambda i: (-scores[i], i))
+        keep = []
+        for i in order:
+            if len(keep) >= k:
+                break
+            if all(not (iou(boxes[i], boxes[j]) > np.float32(thr)) for j in keep):
+                keep.append(i)
+        assert list(tfops.non_max_suppression_fast(boxes, scores, k, thr)) == keep
