@@ -379,7 +379,8 @@ wino3x3_f32_kernel(const ConvArgs a) {
 
         // ---- epilogue: Y = A^T M A, batch-norm + ReLU, stores (they drain under the next
         //      item's first chunk) ----------------------------------------------------------------
-        {
+        // (a.debug & 1, tools/: the kernel without its epilogues -- what they cost)
+        if (!(a.debug & 1)) {
             const Item it = decode(comp_item);
             float* out = a.out + (size_t)it.frame * a.out_frame_stride;
             const int out_rows = a.H - a.out_y0;
