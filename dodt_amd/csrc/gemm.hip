@@ -372,20 +372,22 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
         w_off[k] = ((piece / NT) * 128 + (piece % NT) * 64 + lane) * 16;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
-    auto issue = [&](int st, int buf) {       // scalar arithmetic only (see blds16s)
+    constexpr int kPerStage = (FUSE ? 4 : 2) + 2 * NT;   // copies per wave and stage
+    // copy number n (0 .. kPerStage - 1) of stage st into ring buffer buf: scalar arithmetic only (see blds16s)
+    auto issue_one = [&](int st, int buf, int n) {
         const unsigned sX = lds0 + (unsigned)(buf * kStage) * 4;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        constexpr int kX = FUSE ? 4 : 2;
+        if (n < kX) {
+            const int k = FUSE ? n >> 1 : n;
             const unsigned piece = (unsigned)(wave + 4 * k) * 1024;
-            dodt::blds16s(x_rsrc, x_off[k], st * (kDmaBK * 4), sX + piece);
-            if (FUSE) dodt::blds16s(x2_rsrc, x_off[k], st * (kDmaBK * 4), sX + kDmaXFloats * 4 + piece);
-        }
-#pragma unroll
-        for (int k = 0; k < 2 * NT; ++k)
+            if (FUSE && (n & 1)) dodt::blds16s(x2_rsrc, x_off[k], st * (kDmaBK * 4), sX + kDmaXFloats * 4 + piece);
+            else dodt::blds16s(x_rsrc, x_off[k], st * (kDmaBK * 4), sX + piece);
+        } else {
+            const int k = n - kX;
             dodt::blds16s(w_rsrc, w_off[k], st * (8 * 128 * 16),
                           sX + kDmaXFloats * (FUSE ? 8 : 4) + (unsigned)(wave + 4 * k) * 1024);
+        }
     };
-    constexpr int kPerStage = (FUSE ? 4 : 2) + 2 * NT;   // copies per wave and stage
 
     f32x16 acc[NT];
 #pragma unroll
@@ -410,35 +412,45 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
         if (st + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0f70 | kPerStage);   // vmcnt(kPerStage)
         else __builtin_amdgcn_s_waitcnt(0x0f70);                                  // vmcnt(0)
         __builtin_amdgcn_s_barrier();     // ... for every wave; buffer (BUF + 2) % 3 is free
-        if (st + 2 < nstages) issue(st + 2, (BUF + 2) % kDmaStages);
+        const bool more = st + 2 < nstages;
         const float* sS = smem + BUF * kStage;
-        f32x4 xf[4], wf[4][NT];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        f32x4 xf[4], wf[4][NT], x2[FUSE ? 4 : 1];
+        auto read_q = [&](int q) {
             xf[q] = *reinterpret_cast<const f32x4*>(sS + xo[q]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 wf[q][nt] = *reinterpret_cast<const f32x4*>(sS + w_base + q * (2 * kDmaBN * 4) + nt * 128);
-        }
-        f32x4 x2[FUSE ? 4 : 1];
-        if (FUSE) {
+            if (FUSE) x2[q] = *reinterpret_cast<const f32x4*>(sS + kDmaXFloats + xo[q]);
+        };
+        // fragments two k-quads ahead of the MFMAs that use them: only the first pair's LDS latency stands in
+        // front of the stage's first MFMA; the copies of stage st + 2 go out one per group of four MFMAs, in the
+        // matrix pipe's shadow (issued in one burst behind the barrier they held the wave's MFMAs back)
+        read_q(0);
+        read_q(1);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int kPerQ = (kPerStage + 3) / 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x2[q] = *reinterpret_cast<const f32x4*>(sS + kDmaXFloats + xo[q]);
-        }
-        __builtin_amdgcn_sched_barrier(0);     // all fragment reads ahead of the MFMAs
-        if (FUSE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+            if (q + 2 < 4) read_q(q + 2);
+            if (FUSE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xf[q][e] = (xf[q][e] + x2[q][e]) / 2.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[q][s2], wf[q][nt][s2], acc[nt], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int n = q * kPerQ; n < (q + 1) * kPerQ && n < kPerStage; ++n) issue_one(st + 2, (BUF + 2) % kDmaStages, n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto issue = [&](int st, int buf) {
+#pragma unroll
+        for (int n = 0; n < kPerStage; ++n) issue_one(st, buf, n);
     };
     issue(0, 0);
     if (nstages > 1) issue(1, 1);
