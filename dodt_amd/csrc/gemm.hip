@@ -318,7 +318,8 @@ int launch_fc(hipStream_t s, const GemmArgs& a, int Npad) {
 // (Round 3 tried a FOUR-stage ring, 64 KB and still two workgroups per CU, in which a wave reads the
 //  fragments of stage s + 1 under the MFMAs of stage s instead of behind the barrier: 103 TFLOP/s against
 //  this form's 109 at M = 1024, N = K = 2048 -- the LDS latency in front of the MFMAs is not what is
-//  left; removed again.)
+//  left; removed again.  Once the copies were interleaved and the fragments read two k-quads ahead (115 TFLOP/s),
+//  a four-stage ring with the copies three stages ahead was tried again: 109.)
 constexpr int kDmaBM = 64, kDmaBK = 32, kDmaStages = 3;
 constexpr int kDmaXFloats = kDmaBM * kDmaBK;
 
