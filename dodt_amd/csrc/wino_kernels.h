@@ -150,6 +150,22 @@ wino3x3_f32_kernel(const ConvArgs a) {
         }
     };
     constexpr int kCopies = Cfg::kPatchPerWave + (Cfg::kWInstr + 3) / 4;
+    // the same copy with scalar operands only (blds16s): for the issue path between MFMAs
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    const unsigned lds_dummy = lds0 + (unsigned)(2 * Cfg::kBufFloats + 4) * 4;
+    const int w_voff = lane * 16;
+    auto copy_s = [&](int n, int img) {
+        if (n < Cfg::kPatchPerWave) {            // compile-time
+            const int j = wave + 4 * n;
+            const unsigned dst = j < Cfg::kPatchInstr ? lds0 + (unsigned)(img * Cfg::kPatchFloats + j * 256) * 4 : lds_dummy;
+            blds16s(in_rsrc, p_off[n], pch * plane_bytes, dst);
+        } else {
+            const int j = wave + 4 * (n - Cfg::kPatchPerWave);
+            const bool real = j < Cfg::kWInstr;
+            const unsigned dst = real ? lds0 + (unsigned)(2 * Cfg::kPatchFloats + img * Cfg::kWFloats + j * 256) * 4 : lds_dummy;
+            blds16s(w_rsrc, real ? w_voff : kOob, wch * (Cfg::kWFloats * 4) + j * 1024, dst);
+        }
+    };
 
     int comp_item = blockIdx.x;
     if (comp_item >= a.n_items) return;
@@ -262,10 +278,10 @@ wino3x3_f32_kernel(const ConvArgs a) {
                 if (k_stamp == 0 || k_stamp == 11)    // 100 MHz reference beside it, to calibrate
                     a.counter_base[32 + 72 + (k_stamp != 0)] = (int)__builtin_amdgcn_s_memrealtime();
             }
-            if (!(a.debug & 2)) {
-#pragma unroll
-                for (int n = 0; n < kCopies; ++n) copy_n(n, PAR ^ 1, PAR ^ 1);
-            }
+            // The copies of chunk k+1 (both images PAR ^ 1: free since the barrier that ended the previous step)
+            // go out one per point over the first points of the MFMA loop below (so that they have the rest of the
+            // step to land), with scalar operands only, in the matrix pipe's shadow -- issued as one burst at the top of the step (round 2) they held this wave's MFMAs back by
+            // their issue time, 400-790 cycles of a 4 800-cycle step.
             if (stamp) stamps[1] = (int)__builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) {
@@ -279,18 +295,28 @@ wino3x3_f32_kernel(const ConvArgs a) {
                     // make the transform's end observable: the stamp depends on its result
                     stamps[2] = (int)__builtin_amdgcn_s_memtime() + (vnext[0][15][1] == 12345.f);
                 }
+                // weight fragments one point ahead of the MFMAs that use them (the scheduling barriers that
+                // pin the copies would otherwise leave each read's latency in front of its MFMAs)
+                f32x4 wq[2][CB / 2];
+#pragma unroll
+                for (int cp = 0; cp < CB / 2; ++cp) wq[0][cp] = *reinterpret_cast<const f32x4*>(sW + cp * 64);
 #pragma unroll
                 for (int x = 0; x < 16; ++x) {
-                    f32x4 wq[CB / 2];
+                    if (x + 1 < 16) {
 #pragma unroll
-                    for (int cp = 0; cp < CB / 2; ++cp)
-                        wq[cp] = *reinterpret_cast<const f32x4*>(sW + (x * 4 * (CB / 2) + cp) * 64);
+                        for (int cp = 0; cp < CB / 2; ++cp)
+                            wq[(x + 1) & 1][cp] =
+                                *reinterpret_cast<const f32x4*>(sW + ((x + 1) * 4 * (CB / 2) + cp) * 64);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb)
-                            acc[tb][cb][x] = mfma16(wq[cb >> 1][(cb & 1) * 2 + s2], vnext[0][x][s2],
+                            acc[tb][cb][x] = mfma16(wq[x & 1][cb >> 1][(cb & 1) * 2 + s2], vnext[0][x][s2],
                                                     acc[tb][cb][x]);
+                    if (tb == 0 && x < kCopies && !(a.debug & 2)) copy_s(x, PAR ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
