@@ -295,25 +295,29 @@ wino3x3_f32_kernel(const ConvArgs a) {
                     // make the transform's end observable: the stamp depends on its result
                     stamps[2] = (int)__builtin_amdgcn_s_memtime() + (vnext[0][15][1] == 12345.f);
                 }
-                // weight fragments one point ahead of the MFMAs that use them (the scheduling barriers that
+                // weight fragments two points ahead of the MFMAs that use them (the scheduling barriers that
                 // pin the copies would otherwise leave each read's latency in front of its MFMAs)
-                f32x4 wq[2][CB / 2];
+                constexpr int kWAhead = 2;
+                f32x4 wq[kWAhead + 1][CB / 2];
 #pragma unroll
-                for (int cp = 0; cp < CB / 2; ++cp) wq[0][cp] = *reinterpret_cast<const f32x4*>(sW + cp * 64);
+                for (int i = 0; i < kWAhead; ++i)
+#pragma unroll
+                    for (int cp = 0; cp < CB / 2; ++cp)
+                        wq[i][cp] = *reinterpret_cast<const f32x4*>(sW + (i * 4 * (CB / 2) + cp) * 64);
 #pragma unroll
                 for (int x = 0; x < 16; ++x) {
-                    if (x + 1 < 16) {
+                    if (x + kWAhead < 16) {
 #pragma unroll
                         for (int cp = 0; cp < CB / 2; ++cp)
-                            wq[(x + 1) & 1][cp] =
-                                *reinterpret_cast<const f32x4*>(sW + ((x + 1) * 4 * (CB / 2) + cp) * 64);
+                            wq[(x + kWAhead) % (kWAhead + 1)][cp] =
+                                *reinterpret_cast<const f32x4*>(sW + ((x + kWAhead) * 4 * (CB / 2) + cp) * 64);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb)
-                            acc[tb][cb][x] = mfma16(wq[x & 1][cb >> 1][(cb & 1) * 2 + s2], vnext[0][x][s2],
+                            acc[tb][cb][x] = mfma16(wq[x % (kWAhead + 1)][cb >> 1][(cb & 1) * 2 + s2], vnext[0][x][s2],
                                                     acc[tb][cb][x]);
                     if (tb == 0 && x < kCopies && !(a.debug & 2)) copy_s(x, PAR ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
