@@ -33,6 +33,17 @@ class EarlyFusionFcLayers(object):
                                           True, dtype=dtype) for k in names]
         self.outputs = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], False, dtype=dtype)
                         for k in outputs]
+        # build_output_layers' layers all read fc_drop (fusion_fc_layers.py:94-133): one layer with the
+        # weights side by side and one launch whose columns go to the separate outputs (fp32 heads)
+        self.fused_out = None
+        if len(outputs) > 1:
+            w = np.concatenate([np.asarray(params[k]['w'], np.float32) for k in outputs], 1)
+            b = np.concatenate([np.asarray(params[k]['b'], np.float32) for k in outputs])
+            fused = ops.FullyConnected(ctx, w, b, False, dtype=dtype)
+            if fused.can_split():
+                self.fused_out = fused
+            else:
+                fused.close()
         self.width = max(l.N for l in self.hidden)
         self.ctx = ctx
 
@@ -56,6 +67,9 @@ class EarlyFusionFcLayers(object):
             y = scratch[i & 1]
             l.forward(x, n, y, ldx=ldx, ldy=self.width, d_x2=x2, d_m=d_n, ctx=ctx)
             x, x2, ldx = y, None, self.width
+        if self.fused_out is not None and ldx % 4 == 0:
+            self.fused_out.forward_split(x, n, d_outs, [l.N for l in self.outputs], ldx=ldx, d_m=d_n, ctx=ctx)
+            return
         for l, d_y in zip(self.outputs, d_outs):
             l.forward(x, n, d_y, ldx=ldx, d_m=d_n, ctx=ctx)
 
@@ -65,5 +79,5 @@ class EarlyFusionFcLayers(object):
             - 2.0 * n * (self.in_ld - self.in_k) * self.hidden[0].N
 
     def close(self):
-        for l in self.hidden + self.outputs:
+        for l in self.hidden + self.outputs + ([self.fused_out] if self.fused_out is not None else []):
             l.close()

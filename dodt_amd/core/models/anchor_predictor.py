@@ -25,6 +25,16 @@ class AnchorPredictor(object):
         self.cls8 = ops.FullyConnected(ctx, *mat('cls_fc8'), relu=False, dtype=dtype)
         self.reg8 = ops.FullyConnected(ctx, *mat('reg_fc8'), relu=False, dtype=dtype)
         self.layers = [self.fc6, self.cls7, self.reg7, self.cls8, self.reg8]
+        # the two output layers as one launch over the [cls | reg] rows of fc7: block-diagonal weights
+        # (a branch's columns see zeros for the other branch's activations); fp32 heads
+        (w8c, b8c), (w8r, b8r) = mat('cls_fc8'), mat('reg_fc8')
+        w8 = np.zeros((w8c.shape[0] + w8r.shape[0], w8c.shape[1] + w8r.shape[1]), np.float32)
+        w8[:w8c.shape[0], :w8c.shape[1]] = w8c
+        w8[w8c.shape[0]:, w8c.shape[1]:] = w8r
+        self.out8 = ops.FullyConnected(ctx, w8, np.concatenate([b8c, b8r]), False, dtype=dtype)
+        if not (self.out8.can_split() and w8c.shape[0] == self.width == w8r.shape[0]):
+            self.out8.close()
+            self.out8 = None
         self.ctx = ctx
 
     def make_scratch(self, n_max):
@@ -39,6 +49,9 @@ class AnchorPredictor(object):
         self.cls7.forward(h6, n, h7, ldx=2 * w, ldy=2 * w, ctx=ctx)
         self.reg7.forward(h6.offset(4 * w, (1,)), n, h7.offset(4 * w, (1,)),
                           ldx=2 * w, ldy=2 * w, ctx=ctx)
+        if self.out8 is not None:
+            self.out8.forward_split(h7, n, [d_objectness, d_offsets], [self.cls8.N, self.reg8.N], ctx=ctx)
+            return
         self.cls8.forward(h7, n, d_objectness, ldx=2 * w, ctx=ctx)
         self.reg8.forward(h7.offset(4 * w, (1,)), n, d_offsets, ldx=2 * w, ctx=ctx)
 
@@ -46,5 +59,5 @@ class AnchorPredictor(object):
         return sum(l.flops(n) for l in self.layers)
 
     def close(self):
-        for l in self.layers:
+        for l in self.layers + ([self.out8] if self.out8 is not None else []):
             l.close()

@@ -507,6 +507,98 @@ int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
     return DODT_OK;
 }
 
+// ---- the skinny layers (N <= 32: the heads' output layers, 2048 -> 2 / 10 / 2 / 3, and the RPN's
+//      256 -> 2 / 6) ---------------------------------------------------------------------------------
+// On the tiled kernels such a layer is ceil(M / 128) workgroups that each walk all of K: 8 workgroups
+// and 49 us at M = 1024, K = 2048 -- latency, not work (the layer reads 8 MB).  Here a workgroup is 16
+// samples x all 32 columns with K SPLIT over its eight waves (wave w takes the 16-k steps w, w + 8, ...: the
+// eight waves read 512 contiguous bytes of a sample row), operands straight from global memory four steps
+// ahead, v_mfma_f32_16x16x4_f32 with the samples as A operand; the eight partial tiles are added in
+// wave order through LDS.  The columns may go to up to three dense arrays (`SplitOut`): the output layers
+// of a head -- cls | offsets | angle vectors -- are then ONE layer with concatenated weights and one launch.
+struct SplitOut {
+    float* y[3];
+    int n_end[3];     // columns [n_end[p-1], n_end[p]) go to y[p]
+    int ld[3];
+};
+
+__device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(512)
+fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
+    __shared__ f32x4 s_part[8][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int M = a.d_m ? min(*a.d_m, a.M) : a.M;
+    const int m0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    // A operand: lane (g, i) holds sample m0 + i at k-slot g; a 16-byte load covers the slot's four k of a step
+    const float* xr = a.x + (size_t)min(m0 + i, M - 1) * a.ldx + 4 * g;
+    // B operand: lane (g, n) holds column n (and n + 16) at k-slot g: blocked [K/8][h][32][4], k = 8q + 4h + s
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w) + ((g >> 1) * 2 + (g & 1)) * 32 + i;
+    const int steps = a.K / 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    for (int j0 = wave; j0 < steps; j0 += 8 * U) {
+        f32x4 xv[U], wa[U], wb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 8 * u;
+            const bool ok = j < steps;
+            const int jj = ok ? j : wave;
+            xv[u] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            wa[u] = ok ? w4[(size_t)jj * 128] : z;          // a step = 2 q = 4 (q, h) planes of 32 float4
+            wb[u] = ok ? w4[(size_t)jj * 128 + 16] : z;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = mfma16x4(xv[u][s], wa[u][s], acc0);
+                acc1 = mfma16x4(xv[u][s], wb[u][s], acc1);
+            }
+    }
+    s_part[wave][0][lane] = acc0;
+    s_part[wave][1][lane] = acc1;
+    __syncthreads();
+    if (tid >= 128) return;
+    const int nb = tid >> 6;
+    f32x4 sum = s_part[0][nb][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) sum += s_part[w][nb][lane];
+    const int n = nb * 16 + i;                  // lane (g, i): samples m0 + 4 g + r, column n
+    if (n >= a.N) return;
+    const float b = a.bias[n];
+    const int p = (n >= so.n_end[0]) + (n >= so.n_end[1]);
+    float* y = p == 0 ? so.y[0] : (p == 1 ? so.y[1] : so.y[2]);
+    const int ld = p == 0 ? so.ld[0] : (p == 1 ? so.ld[1] : so.ld[2]);
+    const int nn = n - (p == 0 ? 0 : (p == 1 ? so.n_end[0] : so.n_end[1]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * g + r;
+        if (m < M) {
+            float v = sum[r] + b;
+            if (a.relu) v = fmaxf(v, 0.0f);
+            y[(size_t)m * ld + nn] = v;
+        }
+    }
+}
+
+// the conditions of fc_skinny_kernel (fp32, weights blocked for BN = 32, no second input)
+bool skinny_ok(int Npad, int K, const GemmArgs& a) {
+    static const bool on = !(getenv("DODT_FC_SKINNY") && atoi(getenv("DODT_FC_SKINNY")) == 0);
+    return on && Npad == 32 && K % 16 == 0 && a.ldx % 4 == 0 && (size_t)a.x % 16 == 0 && !a.x2;
+}
+
+int launch_fc_skinny(hipStream_t s, const GemmArgs& a, const SplitOut& so) {
+    hipLaunchKernelGGL(fc_skinny_kernel, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
 }  // namespace
 
 // (a + b) / 2 of two row-major blocks, rows limited by *d_n: the heads' "mean" fusion of BEV and image
@@ -638,7 +730,39 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
         if (tile == 32) return launch_fc<64, 128, 2, 2, 128, 32>(s, a, f->Npad);
         return launch_fc<64, 128, 2, 2, 128, 64>(s, a, f->Npad);
     }
+    if (skinny_ok(f->Npad, f->K, a)) {
+        SplitOut so = {{d_y, d_y, d_y}, {f->N, f->N, f->N}, {ldy, ldy, ldy}};
+        return launch_fc_skinny(s, a, so);
+    }
     return launch_fc<128, 32, 4, 1>(s, a, f->Npad);
+}
+
+int dodt_fc_forward_split(dodt_fc* f, dodt_ctx* ctx, const float* d_x, int ldx, int M, const int32_t* d_m,
+                          int parts, const int* widths, float* const* d_ys) {
+    DODT_REQUIRE(f && d_x && widths && d_ys, "dodt_fc_forward_split: NULL argument");
+    DODT_REQUIRE(parts >= 1 && parts <= 3, "dodt_fc_forward_split: %d parts (1..3)", parts);
+    DODT_REQUIRE(M >= 0 && ldx >= f->K, "dodt_fc_forward_split: bad strides");
+    GemmArgs a;
+    a.x = d_x; a.x2 = nullptr; a.w = f->d_w; a.bias = f->d_b; a.y = nullptr;
+    a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = 0; a.relu = f->relu;
+    a.d_m = d_m;
+    SplitOut so;
+    int end = 0;
+    for (int p = 0; p < 3; ++p) {
+        const int q = p < parts ? p : parts - 1;
+        DODT_REQUIRE(widths[q] >= 1 && d_ys[q], "dodt_fc_forward_split: part %d is empty", q);
+        if (p < parts) end += widths[p];
+        so.y[p] = d_ys[q];
+        so.n_end[p] = p < parts ? end : f->N + 1;
+        so.ld[p] = widths[q];
+    }
+    DODT_REQUIRE(end == f->N, "dodt_fc_forward_split: the parts have %d columns, the layer %d", end, f->N);
+    if (f->bf16 || !skinny_ok(f->Npad, f->K, a)) {
+        dodt::set_error("dodt_fc_forward_split: fp32 layers with N <= 32, K %% 16 == 0 and 16-byte aligned rows only");
+        return DODT_ERR_UNSUPPORTED;
+    }
+    if (M == 0) return DODT_OK;
+    return launch_fc_skinny((ctx ? ctx : f->ctx)->stream, a, so);
 }
 
 double dodt_fc_flops(const dodt_fc* f, int M) {

@@ -4,6 +4,7 @@ These are what the frame-pair pipeline is made of; the avod.core-shaped host API
 in dodt_amd/core/ wraps them with numpy upload/download.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -199,7 +200,7 @@ class FullyConnected(object):
         b = np.ascontiguousarray(b, dtype=np.float32)
         if w.ndim != 2 or b.shape != (w.shape[1],):
             raise ValueError('weights must be (K,N) and bias (N,)')
-        self.ctx, self.K, self.N = ctx, int(w.shape[0]), int(w.shape[1])
+        self.ctx, self.K, self.N, self.dtype = ctx, int(w.shape[0]), int(w.shape[1]), dtype
         h = C.c_void_p()
         flags = (_lib.FC_RELU if relu else 0) | (_lib.FC_BF16 if dtype == 'bf16' else 0)
         _lib.check(ctx.lib.dodt_fc_create_ex(ctx.handle, self.K, self.N,
@@ -213,6 +214,20 @@ class FullyConnected(object):
         _lib.check(c.lib.dodt_fc_forward(
             self.handle, c.handle, _p(d_x), _p(d_x2), int(self.K if ldx is None else ldx),
             int(M), _p(d_m), _p(d_y), int(self.N if ldy is None else ldy)), 'dodt_fc_forward')
+
+    def can_split(self, ldx=None):
+        """Whether forward_split takes this layer (dodt_fc_forward_split's conditions)."""
+        return self.dtype == 'f32' and self.N <= 32 and self.K % 16 == 0 and \
+            (self.K if ldx is None else ldx) % 4 == 0 and os.environ.get('DODT_FC_SKINNY') != '0'
+
+    def forward_split(self, d_x, M, d_ys, widths, ldx=None, d_m=None, ctx=None):
+        """One launch, columns [0, widths[0]) to d_ys[0] (M, widths[0]), the next widths[1] to d_ys[1], ..."""
+        c = ctx or self.ctx
+        w = (C.c_int * len(widths))(*[int(v) for v in widths])
+        ys = (C.c_void_p * len(d_ys))(*[_p(y) for y in d_ys])
+        _lib.check(c.lib.dodt_fc_forward_split(
+            self.handle, c.handle, _p(d_x), int(self.K if ldx is None else ldx), int(M), _p(d_m),
+            len(widths), w, ys), 'dodt_fc_forward_split')
 
     def flops(self, M):
         return 2.0 * M * self.K * self.N

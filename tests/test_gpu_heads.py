@@ -67,6 +67,9 @@ def test_correlation_full_size_properties(ctx):
     (1000, 2048, 10, False, False),    # off_out
     (513, 1225, 2048, True, False),    # corr fc6: K not a multiple of 4
     (1, 40, 3, False, False), (64, 32, 128, True, False),
+    # the split-K kernel of the skinny layers (N <= 32, K % 16 == 0): few steps, ragged M, ReLU, 32 columns
+    (1024, 2048, 2, False, False), (37, 16, 5, True, False), (5, 48, 32, False, False),
+    (2000, 528, 17, True, False),
     # the LDS-DMA staged kernel (K % 32 == 0, 128-wide blocking): ragged M, two-stage K, fusion
     (1000, 2048, 2048, True, False), (130, 64, 128, False, False), (513, 96, 256, True, True)])
 def test_fully_connected_matches_oracle(ctx, M, K, N, relu, fuse):
@@ -122,6 +125,37 @@ def test_fully_connected_strides_and_device_row_count(ctx):
     with pytest.raises(ValueError):
         fc.forward(ctx.array(xs), M, d_y, ldx=100, ldy=ldy)
     fc.close()
+
+
+@pytest.mark.parametrize('M,K,widths,ldx,rows', [
+    (1024, 2048, (2, 10, 2), 2048, 1000),     # a stage-2 head's cls | offsets | angle vectors
+    (700, 512, (2, 6), 512, None),            # the RPN's objectness | offsets
+    (33, 64, (3,), 80, 20), (100, 32, (1, 30, 1), 32, None)])
+def test_fully_connected_split_outputs(ctx, M, K, widths, ldx, rows):
+    """One launch, columns to separate dense arrays (dodt_fc_forward_split) = the layers run one by one."""
+    rng = np.random.default_rng(M + K)
+    N = sum(widths)
+    xs = rng.normal(size=(M, ldx)).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / K), size=(K, N)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=N).astype(np.float32)
+    fc = ops.FullyConnected(ctx, w, b, False)
+    assert fc.can_split(ldx)
+    d_ys = [ctx.array(np.full((M, n), 7.0, np.float32)) for n in widths]
+    d_m = None if rows is None else ctx.array(np.array([rows], np.int32))
+    fc.forward_split(ctx.array(xs), M, d_ys, widths, ldx=ldx, d_m=d_m)
+    want = oheads.fc(xs[:, :K], w, b, False)
+    lim, c0 = M if rows is None else rows, 0
+    for d_y, n in zip(d_ys, widths):
+        got = d_y.download()
+        _close(got[:lim], want[:lim, c0:c0 + n])
+        assert np.all(got[lim:] == 7.0)
+        c0 += n
+    with pytest.raises(ValueError):
+        fc.forward_split(ctx.array(xs), M, d_ys, [w_ + 1 for w_ in widths], ldx=ldx)
+    fc.close()
+    wide = ops.FullyConnected(ctx, rng.normal(size=(K, 40)).astype(np.float32), np.zeros(40, np.float32), False)
+    assert not wide.can_split()
+    wide.close()
 
 
 @pytest.mark.parametrize('conv_dtype,head_dtype', [('f32', 'f32'), ('f32s', 'f32'),

@@ -81,7 +81,9 @@ def _nms_case(rng, n, scale):
     (1, 10, 0.5, 0.1), (2, 1, 0.5, 0.1), (63, 100, 0.5, 0.2), (64, 64, 0.3, 0.2),
     (65, 1000, 0.8, 0.2), (1000, 100, 0.01, 0.05), (2048, 300, 0.8, 0.1),
     (2049, 1024, 0.8, 0.1), (4100, 1024, 0.5, 0.05), (8192, 1024, 0.8, 0.03),
-    (9000, 300, 0.8, 0.03), (14000, 1024, 0.8, 0.03), (20000, 2000, 0.6, 0.02)])
+    (9000, 300, 0.8, 0.03), (14000, 1024, 0.8, 0.03), (20000, 2000, 0.6, 0.02),
+    # many chunks of rows on the counted-rank path; the bitonic path above 32768 candidates
+    (16000, 1024, 0.3, 0.1), (40000, 700, 0.7, 0.015)])
 def test_nms_matches_oracle(n, k, thr, scale):
     rng = np.random.default_rng(n * 31 + k)
     boxes, scores = _nms_case(rng, n, scale)
