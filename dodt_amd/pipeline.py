@@ -197,7 +197,7 @@ class FramePairPipeline(object):
         """Timing mark `name` of step `step` on context c (only for steps in mark_steps)."""
         if step in self.mark_steps:
             slot = sum(1 for (cc, _) in self.marks.values() if cc is c)
-            if slot < 16:
+            if slot < 64:
                 c.mark(slot)
                 self.marks['%d:%s' % (step, name)] = (c, slot)
 

@@ -11,10 +11,11 @@ from dodt_amd.pipeline import FramePairPipeline  # noqa: E402
 
 computed = '--injected' not in sys.argv
 conv_dtype = 'bf16' if '--bf16' in sys.argv else 'f32'
+head_dtype = 'bf16' if '--bf16-heads' in sys.argv else 'f32'
 ctx = device.default_context()
 pipe = FramePairPipeline(ctx, config.PYRAMID_DODT, **synth.pipeline_weights(config.PYRAMID_DODT),
                          head_params=synth.head_params() if computed else None,
-                         conv_dtype=conv_dtype)
+                         conv_dtype=conv_dtype, head_dtype=head_dtype)
 frames = (0, 2)
 pts = [ctx.array(synth.lidar_frame(0, f)) for f in frames]
 imgs = [ctx.array(synth.image_frame(0, f)) for f in frames]
@@ -23,7 +24,7 @@ heads = None if computed else [{k: ctx.array(v) for k, v in
                                for f in frames]
 n = [120000, 120000]
 T = 8
-pipe.mark_steps = (T,)          # 16 marks per context: one step's stages
+pipe.mark_steps = (T, T + 1) if '--two' in sys.argv else (T,)
 for i in range(T + 4):
     pipe.run(pts, n, imgs, heads)
 pipe.finish()
