@@ -526,6 +526,12 @@ __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// (BF16: the heads' bf16 mode -- x rounded to bf16 on load, weights stored as bf16 [K/16][h][32][8], k = 16q + 8h + s;
+//  one v_mfma_f32_16x16x16_bf16 per step and column block, k-slot g = k 4g .. 4g+3 of the step)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF16>
 __global__ void __launch_bounds__(512)
 fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
     __shared__ f32x4 s_part[8][2][64];
@@ -536,30 +542,57 @@ fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
     if (m0 >= M) return;
     // A operand: lane (g, i) holds sample m0 + i at k-slot g; a 16-byte load covers the slot's four k of a step
     const float* xr = a.x + (size_t)min(m0 + i, M - 1) * a.ldx + 4 * g;
-    // B operand: lane (g, n) holds column n (and n + 16) at k-slot g: blocked [K/8][h][32][4], k = 8q + 4h + s
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w) + ((g >> 1) * 2 + (g & 1)) * 32 + i;
     const int steps = a.K / 16;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
-    for (int j0 = wave; j0 < steps; j0 += 8 * U) {
-        f32x4 xv[U], wa[U], wb[U];
+    if constexpr (BF16) {
+        // B operand: lane (g, n): column n (and n + 16), 8 bytes = k 4g .. 4g+3 of the step
+        const f32x2* w2 = reinterpret_cast<const f32x2*>(a.w) + ((g >> 1) * 32 + i) * 2 + (g & 1);
+        for (int j0 = wave; j0 < steps; j0 += 8 * U) {
+            f32x4 xv[U];
+            f32x2 wa[U], wb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 8 * u;
-            const bool ok = j < steps;
-            const int jj = ok ? j : wave;
-            xv[u] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            wa[u] = ok ? w4[(size_t)jj * 128] : z;          // a step = 2 q = 4 (q, h) planes of 32 float4
-            wb[u] = ok ? w4[(size_t)jj * 128 + 16] : z;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = mfma16x4(xv[u][s], wa[u][s], acc0);
-                acc1 = mfma16x4(xv[u][s], wb[u][s], acc1);
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 8 * u;
+                const bool ok = j < steps;
+                const int jj = ok ? j : wave;
+                xv[u] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+                const f32x2 z = {0.f, 0.f};
+                wa[u] = ok ? w2[(size_t)jj * 128] : z;           // a step = 2 h-planes of 32 x 16 bytes
+                wb[u] = ok ? w2[(size_t)jj * 128 + 32] : z;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x2 xb = {pack_bf16(xv[u][0], xv[u][1]), pack_bf16(xv[u][2], xv[u][3])};
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, xb),
+                                                                 __builtin_bit_cast(s16x4, wa[u]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, xb),
+                                                                 __builtin_bit_cast(s16x4, wb[u]), acc1, 0, 0, 0);
+            }
+        }
+    } else {
+        // B operand: lane (g, n) holds column n (and n + 16) at k-slot g: blocked [K/8][h][32][4], k = 8q + 4h + s
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w) + g * 32 + i;
+        for (int j0 = wave; j0 < steps; j0 += 8 * U) {
+            f32x4 xv[U], wa[U], wb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 8 * u;
+                const bool ok = j < steps;
+                const int jj = ok ? j : wave;
+                xv[u] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                wa[u] = ok ? w4[(size_t)jj * 128] : z;          // a step = 2 q = 4 (q, h) planes of 32 float4
+                wb[u] = ok ? w4[(size_t)jj * 128 + 16] : z;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = mfma16x4(xv[u][s], wa[u][s], acc0);
+                    acc1 = mfma16x4(xv[u][s], wb[u][s], acc1);
+                }
+        }
     }
     s_part[wave][0][lane] = acc0;
     s_part[wave][1][lane] = acc1;
@@ -587,14 +620,15 @@ fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
     }
 }
 
-// the conditions of fc_skinny_kernel (fp32, weights blocked for BN = 32, no second input)
+// the conditions of fc_skinny_kernel (weights blocked for BN = 32, no second input)
 bool skinny_ok(int Npad, int K, const GemmArgs& a) {
     static const bool on = !(getenv("DODT_FC_SKINNY") && atoi(getenv("DODT_FC_SKINNY")) == 0);
     return on && Npad == 32 && K % 16 == 0 && a.ldx % 4 == 0 && (size_t)a.x % 16 == 0 && !a.x2;
 }
 
-int launch_fc_skinny(hipStream_t s, const GemmArgs& a, const SplitOut& so) {
-    hipLaunchKernelGGL(fc_skinny_kernel, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
+int launch_fc_skinny(hipStream_t s, const GemmArgs& a, const SplitOut& so, bool bf16) {
+    if (bf16) hipLaunchKernelGGL(fc_skinny_kernel<true>, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
+    else hipLaunchKernelGGL(fc_skinny_kernel<false>, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
 }
@@ -711,6 +745,10 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
     a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = ldy; a.relu = f->relu;
     a.d_m = d_m;
     hipStream_t s = (ctx ? ctx : f->ctx)->stream;
+    if (skinny_ok(f->Npad, f->K, a)) {
+        SplitOut so = {{d_y, d_y, d_y}, {f->N, f->N, f->N}, {ldy, ldy, ldy}};
+        return launch_fc_skinny(s, a, so, f->bf16);
+    }
     if (f->bf16) {
         if (f->BN == 128) return launch_fc<64, 128, 2, 2, 128, 128, true>(s, a, f->Npad);
         return launch_fc<128, 32, 4, 1, 32, 64, true>(s, a, f->Npad);
@@ -729,10 +767,6 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
         if (tile == 64) return launch_fc<64, 64, 2, 2, 128>(s, a, f->Npad);
         if (tile == 32) return launch_fc<64, 128, 2, 2, 128, 32>(s, a, f->Npad);
         return launch_fc<64, 128, 2, 2, 128, 64>(s, a, f->Npad);
-    }
-    if (skinny_ok(f->Npad, f->K, a)) {
-        SplitOut so = {{d_y, d_y, d_y}, {f->N, f->N, f->N}, {ldy, ldy, ldy}};
-        return launch_fc_skinny(s, a, so);
     }
     return launch_fc<128, 32, 4, 1>(s, a, f->Npad);
 }
@@ -757,12 +791,12 @@ int dodt_fc_forward_split(dodt_fc* f, dodt_ctx* ctx, const float* d_x, int ldx, 
         so.ld[p] = widths[q];
     }
     DODT_REQUIRE(end == f->N, "dodt_fc_forward_split: the parts have %d columns, the layer %d", end, f->N);
-    if (f->bf16 || !skinny_ok(f->Npad, f->K, a)) {
-        dodt::set_error("dodt_fc_forward_split: fp32 layers with N <= 32, K %% 16 == 0 and 16-byte aligned rows only");
+    if (!skinny_ok(f->Npad, f->K, a)) {
+        dodt::set_error("dodt_fc_forward_split: layers with N <= 32, K %% 16 == 0 and 16-byte aligned rows only");
         return DODT_ERR_UNSUPPORTED;
     }
     if (M == 0) return DODT_OK;
-    return launch_fc_skinny((ctx ? ctx : f->ctx)->stream, a, so);
+    return launch_fc_skinny((ctx ? ctx : f->ctx)->stream, a, so, f->bf16);
 }
 
 double dodt_fc_flops(const dodt_fc* f, int M) {

@@ -217,7 +217,7 @@ class FullyConnected(object):
 
     def can_split(self, ldx=None):
         """Whether forward_split takes this layer (dodt_fc_forward_split's conditions)."""
-        return self.dtype == 'f32' and self.N <= 32 and self.K % 16 == 0 and \
+        return self.N <= 32 and self.K % 16 == 0 and \
             (self.K if ldx is None else ldx) % 4 == 0 and os.environ.get('DODT_FC_SKINNY') != '0'
 
     def forward_split(self, d_x, M, d_ys, widths, ldx=None, d_m=None, ctx=None):

@@ -340,7 +340,7 @@ int dodt_fc_forward(dodt_fc* fc, dodt_ctx* ctx, const float* d_x, const float* d
 /* A layer whose columns go to `parts` (1..3) dense arrays d_ys[p] of (M, widths[p]) floats, widths summing to
  * the layer's N: the output layers of a head (fusion_fc_layers.py:94-133 build_output_layers: cls | offsets |
  * angle vectors from the same fc_drop) created as ONE layer with concatenated weights and run as one launch.
- * fp32 layers with N <= 32, K a multiple of 16 and 16-byte aligned rows (ldx % 4 == 0); else
+ * Layers with N <= 32, K a multiple of 16 and 16-byte aligned rows (ldx % 4 == 0); else
  * DODT_ERR_UNSUPPORTED. */
 int dodt_fc_forward_split(dodt_fc* fc, dodt_ctx* ctx, const float* d_x, int ldx, int M, const int32_t* d_m,
                           int parts, const int* widths, float* const* d_ys);

@@ -153,6 +153,14 @@ def test_fully_connected_split_outputs(ctx, M, K, widths, ldx, rows):
     with pytest.raises(ValueError):
         fc.forward_split(ctx.array(xs), M, d_ys, [w_ + 1 for w_ in widths], ldx=ldx)
     fc.close()
+    # the bf16 heads' form of the same launch, against the oracle's bf16 restatement
+    fc = ops.FullyConnected(ctx, w, b, False, dtype='bf16')
+    fc.forward_split(ctx.array(xs), M, d_ys, widths, ldx=ldx, d_m=d_m)
+    want, c0 = oheads.fc(xs[:, :K], w, b, False, dtype='bf16'), 0
+    for d_y, n in zip(d_ys, widths):
+        _close(d_y.download()[:lim], want[:lim, c0:c0 + n])
+        c0 += n
+    fc.close()
     wide = ops.FullyConnected(ctx, rng.normal(size=(K, 40)).astype(np.float32), np.zeros(40, np.float32), False)
     assert not wide.can_split()
     wide.close()
