@@ -73,6 +73,14 @@ struct WinoCfg {
     static constexpr int kPatchPerWave = (kPatchInstr + 3) / 4;
 };
 
+// a - b on a register pair in one instruction (the compiler splits a v2f32 subtraction into two v_sub_f32)
+typedef float wino_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wino_f32x2 pk_sub(wino_f32x2 a, wino_f32x2 b) {
+    wino_f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -411,90 +419,113 @@ wino3x3_f32_kernel(const ConvArgs a) {
         //      item's first chunk) ----------------------------------------------------------------
         // (a.debug & 1, tools/: the kernel without its epilogues -- what they cost)
         if (!(a.debug & 1)) {
+            // The epilogue's arguments come from the kernarg segment again (scalar loads, through a pointer the
+            // compiler cannot see through): kept in SGPRs across the K loop they are spilled to vector lanes and
+            // every item pays ~100 v_readlane for them on the vector pipe the MFMAs of the other workgroup need.
+            typedef const ConvArgs __attribute__((address_space(4))) KernArgs;
+            KernArgs* ep_ = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ep_));
+            KernArgs& e = *ep_;
             const Item it = decode(comp_item);
-            float* out = a.out + (size_t)it.frame * a.out_frame_stride;
-            const int out_rows = a.H - a.out_y0;
-            const long long plane = (long long)out_rows * a.W * 8;
-            const bool pool = a.pool_out != nullptr;
-            const long long pplane = (long long)(a.H >> 1) * (a.W >> 1) * 8;
+            float* out = e.out + (size_t)it.frame * e.out_frame_stride;
+            const int out_rows = e.H - e.out_y0;
+            const long long plane = (long long)out_rows * e.W * 8;
+            const bool pool = e.pool_out != nullptr;
+            const long long pplane = (long long)(e.H >> 1) * (e.W >> 1) * 8;
+            // every pixel of the tile is stored: no per-pixel tests (scalar condition)
+            const bool interior = it.ty0 + Cfg::TH <= e.H && it.tx0 + Cfg::TW <= e.W && it.ty0 >= e.out_y0;
+            const float relu_floor = e.relu ? 0.0f : -__builtin_inff();
+            typedef wino_f32x2 f32x2;
 #pragma unroll
             for (int tb = 0; tb < TB; ++tb) {
                 const int oy0 = it.ty0 + 2 * (2 * (wave * TB + tb) + tyl);
                 const int ox0 = it.tx0 + 2 * txl;
+                // CB8 maps: the lane's cell offset inside a PAIR of channel planes (plane g >> 1, floats 4 (g & 1) ..
+                // of the 32-byte cell), in floats -- a frame's planes stay below 2^31 floats; the pair's base is scalar
+                const int w8 = e.W * 8;
+                const int cell = (g >> 1) * (int)plane + ((oy0 - e.out_y0) * e.W + ox0) * 8 + 4 * (g & 1);
+                const int pcell = (g >> 1) * (int)pplane + ((oy0 >> 1) * (e.W >> 1) + (ox0 >> 1)) * 8 + 4 * (g & 1);
                 float dot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
                     const int c0 = it.ntile * BN + cb * 16 + 4 * g;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(e.scale + c0);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(e.shift + c0);
                     f32x4 y[4];       // outputs (0,0) (0,1) (1,0) (1,1), 4 channels each
-                    {
-                        const f32x4* m = acc[tb][cb];
-                        f32x4 z[4][2];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {      // channel pairs: packed fp32 instructions
+                        auto M = [&](int x) { return f32x2{acc[tb][cb][x][2 * hf], acc[tb][cb][x][2 * hf + 1]}; };
+                        f32x2 z[4][2];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            z[i][0] = (m[i * 4 + 0] + m[i * 4 + 1]) + m[i * 4 + 2];
-                            z[i][1] = (m[i * 4 + 1] - m[i * 4 + 2]) - m[i * 4 + 3];
+                            z[i][0] = (M(i * 4 + 0) + M(i * 4 + 1)) + M(i * 4 + 2);
+                            z[i][1] = pk_sub(pk_sub(M(i * 4 + 1), M(i * 4 + 2)), M(i * 4 + 3));
                         }
+                        const f32x2 sc2 = {sc[2 * hf], sc[2 * hf + 1]}, sh2 = {sh[2 * hf], sh[2 * hf + 1]};
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            y[0 + b] = (z[0][b] + z[1][b]) + z[2][b];
-                            y[2 + b] = (z[1][b] - z[2][b]) - z[3][b];
+                            const f32x2 t0 = ((z[0][b] + z[1][b]) + z[2][b]) * sc2 + sh2;
+                            const f32x2 t1 = pk_sub(pk_sub(z[1][b], z[2][b]), z[3][b]) * sc2 + sh2;
+                            y[0 + b][2 * hf] = fmaxf(t0[0], relu_floor);
+                            y[0 + b][2 * hf + 1] = fmaxf(t0[1], relu_floor);
+                            y[2 + b][2 * hf] = fmaxf(t1[0], relu_floor);
+                            y[2 + b][2 * hf + 1] = fmaxf(t1[1], relu_floor);
                         }
                     }
-                    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+                    if (!e.out_nhwc) {
+                        float* cellp = out + (size_t)((e.out_coff + it.ntile * BN + cb * 16) >> 3) * plane + cell;
+                        if (interior) {
+                            *reinterpret_cast<f32x4*>(cellp) = y[0];
+                            *reinterpret_cast<f32x4*>(cellp + 8) = y[1];
+                            *reinterpret_cast<f32x4*>(cellp + w8) = y[2];
+                            *reinterpret_cast<f32x4*>(cellp + w8 + 8) = y[3];
+                        } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < 4; ++q) {
+                                const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
+                                if (oy < e.H && ox < e.W && oy >= e.out_y0)
+                                    *reinterpret_cast<f32x4*>(cellp + (q >> 1) * w8 + (q & 1) * 8) = y[q];
+                            }
+                        }
+                    } else {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float tv = y[q][k] * sc[k] + sh[k];
-                            y[q][k] = a.relu ? fmaxf(tv, 0.0f) : tv;
+                        for (int q = 0; q < 4; ++q) {
+                            const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
+                            if (oy < e.H && ox < e.W && oy >= e.out_y0)
+                                *reinterpret_cast<f32x4*>(out + ((size_t)(oy - e.out_y0) * e.W + ox) * e.out_ld +
+                                                          e.out_coff + c0) = y[q];
                         }
-                        const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
-                        const bool ok = oy < a.H && ox < a.W && oy >= a.out_y0;
-                        if (ok) {
-                            float* dst;
-                            if (a.out_nhwc)
-                                dst = out + ((size_t)(oy - a.out_y0) * a.W + ox) * a.out_ld +
-                                      a.out_coff + c0;
-                            else
-                                dst = out + (size_t)((a.out_coff + c0) >> 3) * plane +
-                                      ((size_t)(oy - a.out_y0) * a.W + ox) * 8 + (c0 & 7);
-                            *reinterpret_cast<f32x4*>(dst) = y[q];
-                        }
-                        if (q == 0) mx = y[0];
-                        else {
+                    }
+                    if (e.bneck_w) {
+                        const f32x4 bw = *reinterpret_cast<const f32x4*>(e.bneck_w + c0);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], y[q][k]);
-                        }
-                        if (a.bneck_w) {
-                            const f32x4 bw = *reinterpret_cast<const f32x4*>(a.bneck_w + c0);
-                            dot[q] += ((y[q][0] * bw[0] + y[q][1] * bw[1]) + y[q][2] * bw[2]) +
-                                      y[q][3] * bw[3];
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            dot[q] += ((y[q][0] * bw[0] + y[q][1] * bw[1]) + y[q][2] * bw[2]) + y[q][3] * bw[3];
                     }
                     // a lane's 2x2 outputs = one window of the following VALID 2x2 max pool
-                    if (pool && oy0 + 1 < a.H && ox0 + 1 < a.W) {
-                        float* dst = a.pool_out + (size_t)it.frame * a.pool_frame_stride +
-                                     (size_t)(c0 >> 3) * pplane +
-                                     ((size_t)(oy0 >> 1) * (a.W >> 1) + (ox0 >> 1)) * 8 + (c0 & 7);
+                    if (pool && (interior || (oy0 + 1 < e.H && ox0 + 1 < e.W))) {
+                        f32x4 mx;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mx[k] = fmaxf(fmaxf(y[0][k], y[1][k]), fmaxf(y[2][k], y[3][k]));
+                        float* dst = e.pool_out + (size_t)it.frame * e.pool_frame_stride +
+                                     (size_t)((it.ntile * BN + cb * 16) >> 3) * pplane + pcell;
                         *reinterpret_cast<f32x4*>(dst) = mx;
                     }
                     // keep the channel blocks apart: interleaved, their 4 x 64 accumulator
                     // registers would all be live in VGPRs at once
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (a.bneck_w) {    // the other channels of these pixels live in lanes l ^ 16, ^ 32
+                if (e.bneck_w) {    // the other channels of these pixels live in lanes l ^ 16, ^ 32
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float s = dot[q];
                         s += __shfl_xor(s, 16, 64);
                         s += __shfl_xor(s, 32, 64);
                         const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
-                        if (g == 0 && oy < a.H && ox < a.W && oy >= a.out_y0)
-                            a.bneck_out[(size_t)it.frame * a.bneck_frame_stride +
-                                        (size_t)(oy - a.out_y0) * a.W + ox] =
-                                fmaxf(s * a.bneck_scale + a.bneck_shift, 0.0f);
+                        if (g == 0 && oy < e.H && ox < e.W && oy >= e.out_y0)
+                            e.bneck_out[(size_t)it.frame * e.bneck_frame_stride +
+                                        (size_t)(oy - e.out_y0) * e.W + ox] =
+                                fmaxf(s * e.bneck_scale + e.bneck_shift, 0.0f);
                     }
                 }
             }
