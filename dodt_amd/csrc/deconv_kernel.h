@@ -253,32 +253,43 @@ deconv3x3_dma_kernel(const ConvArgs a) {
                              : "+a"(acc[r][0][cb]), "+a"(acc[r][1][cb]), "+a"(acc[r][2][cb]), "+a"(acc[r][3][cb]));
         // ---- epilogue: batch-norm + ReLU, the four parity classes of every input pixel ------------
         {
+            // (arguments from the kernarg segment again, packed multiply / add, one cell offset per lane and no
+            //  per-pixel tests on interior tiles: see the epilogue of wino3x3_f32_kernel)
+            typedef const ConvArgs __attribute__((address_space(4))) KernArgs;
+            KernArgs* ep_ = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ep_));
+            KernArgs& e = *ep_;
             const Item it = decode(comp_item);
-            float* out = a.out + (size_t)it.frame * a.out_frame_stride;
-            const long long plane = (long long)(2 * a.H) * (2 * a.W) * 8;
+            float* out = e.out + (size_t)it.frame * e.out_frame_stride;
+            const long long plane = (long long)(2 * e.H) * (2 * e.W) * 8;
             const int x = it.tx0 + t;
+            const bool interior = it.ty0 + 16 <= e.H && it.tx0 + 16 <= e.W;
+            const float relu_floor = e.relu ? 0.0f : -__builtin_inff();
+            const int row8 = 2 * e.W * 8;                 // floats per output row of a plane
+            // the lane's cell: output pixel (2 y0, 2 x) of its first row, in floats from the plane pair's base
+            const int y0 = it.ty0 + 4 * wave;
+            const int cell = (2 * y0 * 2 * e.W + 2 * x) * 8;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 const int c0 = it.ntile * BN + cb * 16 + 4 * g;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c0);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c0);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(e.scale + c0);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(e.shift + c0);
+                const f32x2_t sc_lo = {sc[0], sc[1]}, sc_hi = {sc[2], sc[3]}, sh_lo = {sh[0], sh[1]}, sh_hi = {sh[2], sh[3]};
                 // CB8 fp32: plane (channel >> 3), float (channel & 7) of the pixel's 8; CB16 bf16: plane
                 // (channel >> 4), the lane's four channels are floats ((channel & 15) >> 1) .. + 1
-                float* obase = BF16 ? out + (size_t)((a.out_coff + c0) >> 4) * plane + (((a.out_coff + c0) & 15) >> 1)
-                                    : out + (size_t)((a.out_coff + c0) >> 3) * plane + ((a.out_coff + c0) & 7);
+                float* obase = BF16 ? out + (size_t)((e.out_coff + c0) >> 4) * plane + (((e.out_coff + c0) & 15) >> 1)
+                                    : out + (size_t)((e.out_coff + c0) >> 3) * plane + ((e.out_coff + c0) & 7);
+                float* cellp = obase + cell;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int y = it.ty0 + 4 * wave + r;
-                    const bool ok = y < a.H && x < a.W;
+                    const bool ok = interior || (y0 + r < e.H && x < e.W);
 #pragma unroll
                     for (int cls = 0; cls < 4; ++cls) {
-                        f32x4 v = acc[r][cls][cb];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float tv = v[k] * sc[k] + sh[k];
-                            v[k] = a.relu ? fmaxf(tv, 0.0f) : tv;
-                        }
-                        float* dst = obase + ((size_t)(2 * y + (cls >> 1)) * (2 * a.W) + 2 * x + (cls & 1)) * 8;
+                        const f32x4 m = acc[r][cls][cb];
+                        const f32x2_t lo = f32x2_t{m[0], m[1]} * sc_lo + sh_lo, hi = f32x2_t{m[2], m[3]} * sc_hi + sh_hi;
+                        const f32x4 v = {fmaxf(lo[0], relu_floor), fmaxf(lo[1], relu_floor), fmaxf(hi[0], relu_floor),
+                                         fmaxf(hi[1], relu_floor)};
+                        float* dst = cellp + (2 * r + (cls >> 1)) * row8 + (cls & 1) * 8;
                         if (ok) {
                             if constexpr (BF16)     // round to nearest even, as every map of the bf16 path
                                 *reinterpret_cast<f32x2_t*>(dst) = f32x2_t{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
