@@ -816,30 +816,54 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
     {
+        // patch + weights -> LDS.  Every load of the thread is issued before the first LDS write (the loop with a
+        // load and its write per trip ran one global-memory latency per trip: 7 trips for the 18 x 34 x 6 patch,
+        // two thirds of the workgroup's life)
         constexpr int CG = CK / VEC;
         constexpr int ITEMS = PH * PW * CG;
-        for (int t = tid; t < ITEMS; t += 256) {
+        constexpr int NIT = (ITEMS + 255) / 256;
+        constexpr int NW = (Cfg::kWFloats / 4 + 255) / 256;
+        float v[NIT][VEC];
+        float4 wv[NW];
+        const float4* wsrc = reinterpret_cast<const float4*>(a.w);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int t = tid + 256 * i;
+            wv[i] = t < Cfg::kWFloats / 4 ? wsrc[t] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int t = tid + 256 * i;
             const int cg = t % CG, p = t / CG;
             const int py = p / PW, px = p - py * PW;
             const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-            float v[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) v[k] = 0.0f;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            for (int k = 0; k < VEC; ++k) v[i][k] = 0.0f;
+            if (t < ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                 const float* src = in + ((size_t)gy * a.W + gx) * a.in_ld + a.in_coff + cg * VEC;
                 if constexpr (VEC == 4) {
                     const float4 q = *reinterpret_cast<const float4*>(src);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                    v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
                 } else {
                     const float2 q = *reinterpret_cast<const float2*>(src);
-                    v[0] = q.x; v[1] = q.y;
+                    v[i][0] = q.x; v[i][1] = q.y;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) sP[(cg * VEC + k) * PS + p] = v[k];
         }
-        const float4* src = reinterpret_cast<const float4*>(a.w);
-        for (int t = tid; t < Cfg::kWFloats / 4; t += 256) reinterpret_cast<float4*>(sW)[t] = src[t];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int t = tid + 256 * i;
+            if (t < Cfg::kWFloats / 4) reinterpret_cast<float4*>(sW)[t] = wv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int t = tid + 256 * i;
+            const int cg = t % CG, p = t / CG;
+            if (t < ITEMS) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) sP[(cg * VEC + k) * PS + p] = v[i][k];
+            }
+        }
     }
     __syncthreads();
     const int x_base = lh * PS + (li / TW) * PW + (li % TW) + wm * MT * Cfg::kRowsPerMT * PW;
