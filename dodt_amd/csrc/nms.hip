@@ -413,11 +413,14 @@ extern "C" int dodt_nms(dodt_ctx* ctx, const float* d_boxes, const float* d_scor
     const int nb = dodt::ceil_div(n, 64);
     const int n_rows = nb * 64;
     const bool ranked = n <= kRankMax;
-    // chunks of candidate rows: the first just over max_out, the others as large as a 32 MB matrix allows
-    const int later_rows = nb <= 512 ? 2 * kChunkRows : kChunkRows;
+    // chunks of candidate rows: the first just over max_out (all of them up to 2048 rows: one mask + scan pair
+    // then), the others as large as a 32 MB matrix allows, at most 4096 (the scan's 64 in-chunk column blocks)
+    const int later_rows = nb <= 1024 ? 2 * kChunkRows : kChunkRows;
     int first_rows = (int)dodt::align_up((size_t)max_out + (size_t)max_out / 8, 64) + 64;
     if (first_rows > later_rows) first_rows = later_rows;
-    if (first_rows > n_rows) first_rows = n_rows;
+    if (first_rows > n_rows || n_rows <= kChunkRows) first_rows = n_rows;
+    // two chunks instead of three where a somewhat longer first one does it (the RPN's 5 760 rows: 1 664 + 4 096)
+    if (n_rows - first_rows > later_rows && n_rows - later_rows <= later_rows) first_rows = n_rows - later_rows;
     const int chunk_rows = n_rows < later_rows ? n_rows : later_rows;    // the largest chunk
     // scratch layout
     size_t off = 0;
