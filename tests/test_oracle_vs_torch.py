@@ -125,3 +125,44 @@ def test_nms_matches_a_quadratic_restatement():
             if all(not (iou(boxes[i], boxes[j]) > np.float32(thr)) for j in keep):
                 keep.append(i)
         assert list(tfops.non_max_suppression_fast(boxes, scores, k, thr)) == keep
+
+
+def test_resize_bilinear_matches_torch_grid_sample_at_the_legacy_coordinates():
+    """TF-1.3's resize_bilinear (align_corners=False, no half-pixel centres) samples at src = dst * in / out,
+    clamped at the last row / column: torch's grid_sample(align_corners=True, padding_mode='border') on exactly
+    those coordinates is an independent bilinear interpolation."""
+    rng = np.random.default_rng(5)
+    h, w, c, oh, ow = 19, 45, 3, 12, 40          # the image path scales down (375x1242 -> 360x1200)
+    img = rng.uniform(0, 255, size=(h, w, c)).astype(np.float32)
+    got = tfops.resize_bilinear(img, oh, ow)
+    sy = np.arange(oh, dtype=np.float64) * h / oh
+    sx = np.arange(ow, dtype=np.float64) * w / ow
+    gy, gx = 2 * sy / (h - 1) - 1, 2 * sx / (w - 1) - 1
+    grid = np.stack([np.broadcast_to(gx[None, :], (oh, ow)), np.broadcast_to(gy[:, None], (oh, ow))], -1)[None]
+    want = F.grid_sample(torch.tensor(img, dtype=torch.float64).permute(2, 0, 1)[None], torch.tensor(grid),
+                         mode='bilinear', padding_mode='border', align_corners=True)[0].permute(1, 2, 0).numpy()
+    _close(got, want, 2e-6)
+    up = tfops.resize_bilinear(img, 2 * h, 2 * w)     # the plain-VGG path scales up: the clamp at the edge
+    assert np.array_equal(up[::2, ::2], img)
+
+
+def test_correlation_matches_an_unfold_formulation():
+    """The same op written the other way round: for every displacement of the (2r+1)^2 grid, the padded second
+    map shifted by it times the first, mean over channels (float64) -- against the oracle's restatement of the
+    CUDA kernel's index arithmetic."""
+    rng = np.random.default_rng(9)
+    h, w, c, d, s2, pad = 13, 17, 8, 4, 2, 4
+    a = rng.normal(size=(h, w, c)).astype(np.float32)
+    b = rng.normal(size=(h, w, c)).astype(np.float32)
+    got = tfops.correlation(a, b, d, s2, pad)
+    r = d // s2
+    ta = torch.tensor(a, dtype=torch.float64).permute(2, 0, 1)
+    tb = F.pad(torch.tensor(b, dtype=torch.float64).permute(2, 0, 1), (d, d, d, d))      # zeros around
+    want = []
+    for p in range(-r, r + 1):
+        for o in range(-r, r + 1):
+            shifted = tb[:, d + p * s2:d + p * s2 + h, d + o * s2:d + o * s2 + w]
+            want.append((ta * shifted).mean(0))
+    want = torch.stack(want, -1).numpy()
+    assert got.shape == want.shape == (h, w, (2 * r + 1) ** 2)     # pad == max_displacement: same size
+    _close(got, want, 2e-6)
