@@ -37,6 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKAlign = 64;   // K is padded to this (the largest stage depth)
+constexpr int kSmallK = 16;   // up to here a layer runs on fc_smallk_kernel
 
 struct GemmArgs {
     const float* x;
@@ -53,6 +54,12 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float pack_bf16(float lo, float hi) {   // round to nearest even
     return __builtin_bit_cast(float, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+// the float value of half `which` (0 = low 16 bits) of a packed bf16 pair
+__device__ __forceinline__ float bf16_value(float packed, int which) {
+    const unsigned u = __builtin_bit_cast(unsigned, packed);
+    return __builtin_bit_cast(float, which ? (u & 0xffff0000u) : (u << 16));
 }
 
 // kBK = k per stage.  BF16: x is rounded to bf16 on its way into LDS, the weights are stored
@@ -620,6 +627,44 @@ fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
     }
 }
 
+// ---- layers with a tiny K (the RPN's 3x3x1 "conv" = FC 9 -> 512 on 5 500 anchors) --------------------------------
+// On the tiled kernel K is padded to a 64-deep stage (seven eighths of the MFMAs multiply zeros) and the register-
+// staged scalar loads keep it at 35 us; the layer is 51 MFLOP and an 11 MB write.  Here a thread owns four
+// consecutive columns of one sample: K multiply-adds each on the vector ALU (float32, k ascending, no fusion), weights
+// [K][N] read as float4 (L1 hits), 16-byte stores along the row.  BF16: the sample (after the mean of the two inputs)
+// and the weights are rounded to bf16 like the tiled bf16 kernel's, products and sums in float32.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+fc_smallk_kernel(const GemmArgs a, const float* __restrict__ w_plain) {
+    const int M = a.d_m ? min(*a.d_m, a.M) : a.M;
+    const int n4 = a.N >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = (int)(t / n4), c = (int)(t - (long long)m * n4) * 4;
+    if (m >= M) return;
+    const float* x = a.x + (size_t)m * a.ldx;
+    const float* x2 = a.x2 ? a.x2 + (size_t)m * a.ldx : nullptr;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < a.K; ++k) {
+        float xv = x[k];
+        if (x2) xv = (xv + x2[k]) / 2.0f;
+        if constexpr (BF16) xv = bf16_value(pack_bf16(xv, 0.0f), 0);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w_plain + (size_t)k * a.N + c);
+        acc += wv * xv;
+    }
+    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + c);
+    acc += b;
+    if (a.relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaxf(acc[i], 0.0f);
+    }
+    float* y = a.y + (size_t)m * a.ldy + c;
+    if ((a.ldy & 3) == 0) *reinterpret_cast<f32x4*>(y) = acc;
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = acc[i];
+    }
+}
+
 // the conditions of fc_skinny_kernel (weights blocked for BN = 32, no second input)
 bool skinny_ok(int Npad, int K, const GemmArgs& a) {
     static const bool on = !(getenv("DODT_FC_SKINNY") && atoi(getenv("DODT_FC_SKINNY")) == 0);
@@ -673,6 +718,7 @@ struct dodt_fc {
     bool bf16 = false;
     float* d_w = nullptr;
     float* d_b = nullptr;
+    float* d_w_plain = nullptr;   // [K][N] as given (bf16 layers: rounded), for K <= kSmallK
 };
 
 extern "C" {
@@ -722,6 +768,19 @@ int dodt_fc_create_ex(dodt_ctx* ctx, int K, int N, const float* w, const float* 
                                   hipMemcpyHostToDevice, ctx->stream));
     DODT_HIP_CHECK(hipMemcpyAsync(f->d_b, b.data(), b.size() * sizeof(float),
                                   hipMemcpyHostToDevice, ctx->stream));
+    std::vector<float> plain;
+    if (K <= kSmallK && N % 4 == 0) {
+        plain.assign(w, w + (size_t)K * N);
+        if (bf16)
+            for (float& v : plain) v = dodt::bf16_to_float(dodt::float_to_bf16(v));
+        if (hipMalloc(&f->d_w_plain, plain.size() * sizeof(float)) != hipSuccess) {
+            dodt::set_error("dodt_fc_create: hipMalloc failed");
+            dodt_fc_destroy(f);
+            return DODT_ERR_HIP;
+        }
+        DODT_HIP_CHECK(hipMemcpyAsync(f->d_w_plain, plain.data(), plain.size() * sizeof(float),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    }
     DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *out = f;
     return DODT_OK;
@@ -731,6 +790,7 @@ int dodt_fc_destroy(dodt_fc* f) {
     if (!f) return DODT_OK;
     if (f->d_w) (void)hipFree(f->d_w);
     if (f->d_b) (void)hipFree(f->d_b);
+    if (f->d_w_plain) (void)hipFree(f->d_w_plain);
     delete f;
     return DODT_OK;
 }
@@ -745,6 +805,18 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
     a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = ldy; a.relu = f->relu;
     a.d_m = d_m;
     hipStream_t s = (ctx ? ctx : f->ctx)->stream;
+    static const bool smallk = !(getenv("DODT_FC_SMALLK") && atoi(getenv("DODT_FC_SMALLK")) == 0);
+    if (smallk && f->d_w_plain && f->N >= 64 && (size_t)d_y % 16 == 0) {
+        const long long threads = (long long)M * (f->N / 4);
+        if (f->bf16)
+            hipLaunchKernelGGL(fc_smallk_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a,
+                               f->d_w_plain);
+        else
+            hipLaunchKernelGGL(fc_smallk_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a,
+                               f->d_w_plain);
+        DODT_LAUNCH_CHECK();
+        return DODT_OK;
+    }
     if (skinny_ok(f->Npad, f->K, a)) {
         SplitOut so = {{d_y, d_y, d_y}, {f->N, f->N, f->N}, {ldy, ldy, ldy}};
         return launch_fc_skinny(s, a, so, f->bf16);

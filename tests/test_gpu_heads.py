@@ -70,6 +70,8 @@ def test_correlation_full_size_properties(ctx):
     # the split-K kernel of the skinny layers (N <= 32, K % 16 == 0): few steps, ragged M, ReLU, 32 columns
     (1024, 2048, 2, False, False), (37, 16, 5, True, False), (5, 48, 32, False, False),
     (2000, 528, 17, True, False),
+    # the vector-ALU kernel of layers with K <= 16 (the RPN's 9 -> 512): no fusion, K = 16, no ReLU
+    (5500, 9, 512, True, False), (37, 16, 64, False, True), (1, 4, 128, False, False),
     # the LDS-DMA staged kernel (K % 32 == 0, 128-wide blocking): ragged M, two-stage K, fusion
     (1000, 2048, 2048, True, False), (130, 64, 128, False, False), (513, 96, 256, True, True)])
 def test_fully_connected_matches_oracle(ctx, M, K, N, relu, fuse):
