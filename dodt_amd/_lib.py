@@ -69,6 +69,7 @@ SIGNATURES = {
     'dodt_last_error': (C.c_char_p, []),
     'dodt_ctx_create': (_i, [_i, C.POINTER(_vp)]),
     'dodt_mark': (_i, [_vp, _i]),
+    'dodt_ctx_wait_mark': (_i, [_vp, _vp, _i]),
     'dodt_mark_elapsed': (_i, [_vp, _i, _vp, _i, C.POINTER(_f)]),
     'dodt_ctx_create_high_priority': (_i, [_i, C.POINTER(_vp)]),
     'dodt_ctx_create_on_stream': (_i, [_i, _vp, C.POINTER(_vp)]),

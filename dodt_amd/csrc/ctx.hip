@@ -135,6 +135,13 @@ int dodt_mark(dodt_ctx* ctx, int slot) {
     return DODT_OK;
 }
 
+int dodt_ctx_wait_mark(dodt_ctx* ctx, dodt_ctx* other, int slot) {
+    DODT_REQUIRE(ctx && other && slot >= 0 && slot < kMarkSlots && other->mark_ev[slot],
+                 "dodt_ctx_wait_mark: bad argument or mark never recorded");
+    DODT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, other->mark_ev[slot], 0));
+    return DODT_OK;
+}
+
 int dodt_mark_elapsed(dodt_ctx* from, int from_slot, dodt_ctx* to, int to_slot, float* ms) {
     DODT_REQUIRE(from && to && ms && from_slot >= 0 && from_slot < kMarkSlots && to_slot >= 0 &&
                      to_slot < kMarkSlots && from->mark_ev[from_slot] && to->mark_ev[to_slot],

@@ -146,6 +146,10 @@ class Context(object):
     def mark(self, slot):
         _lib.check(self.lib.dodt_mark(self.handle, int(slot)), 'dodt_mark')
 
+    def wait_mark(self, other, slot):
+        """Later work on this context waits for `other`'s mark `slot` as last recorded."""
+        _lib.check(self.lib.dodt_ctx_wait_mark(self.handle, other.handle, int(slot)), 'dodt_ctx_wait_mark')
+
     def elapsed_ms(self, slot, to_ctx, to_slot):
         """GPU time from this context's mark `slot` to `to_ctx`'s mark `to_slot`."""
         ms = C.c_float()

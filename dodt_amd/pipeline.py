@@ -190,6 +190,7 @@ class FramePairPipeline(object):
         # read it, at least a ring's half earlier
         self.on_records_reuse = None
         self.mark_steps = ()           # tools/pipe_marks.py: steps whose stages get timing marks
+        self.early_prep = os.environ.get('DODT_PIPE_EARLY_PREP', '1') != '0'
         self.marks = {}                # name -> (context, slot)
         ctx.sync()
 
@@ -329,26 +330,44 @@ class FramePairPipeline(object):
         self._mark(self.img_ctx, k, 'img_end')
         # -- the previous step's tail runs under this step's convs --------------------------
         if self.pending is not None:
+            self._wait_convs(self.pending)
             self._tail(self.pending)
             for i, s in enumerate(self.sides):
                 main.wait_for(s)       # previous step's records are complete on `main`
                 self.preps[i].wait_for(s)   # the NEXT step's prep reuses that tail's buffers
         self.pending = dict(cur=cur, heads=heads, step=k, rslot=k % len(self.rec2))
-        # the tail of THIS step (next call) starts when these convs are done
-        for s in self.sides:
-            s.wait_for(main)
-            s.wait_for(self.img_ctx)
+        # The tail of THIS step (next call) starts when these convs are done.  The point is marked now and waited
+        # for when the tail is enqueued -- behind the NEXT step's prep on the same side stream, which therefore
+        # runs under these convs instead of behind them (DODT_PIPE_EARLY_PREP=0: the wait goes in here, in front
+        # of that prep, as before round 3)
+        if self.early_prep:
+            main.mark(self.CONV_DONE_MARK + cur)
+            self.img_ctx.mark(self.CONV_DONE_MARK + cur)
+        else:
+            for s in self.sides:
+                s.wait_for(main)
+                s.wait_for(self.img_ctx)
         self.step_idx += 1
         return cur
 
     def finish(self):
         """Enqueue the tail of the last step; afterwards self.fr / d_records hold it."""
         if self.pending is not None:
+            self._wait_convs(self.pending)
             self._tail(self.pending)
             self.pending = None
         for s in self.sides:
             self.ctx.wait_for(s)
         self.ctx.wait_for(self.img_ctx)
+
+    CONV_DONE_MARK = 250        # mark slots 250, 251 of the conv contexts: end of a step's stacks, by parity
+
+    def _wait_convs(self, st):
+        """The side streams wait for the conv stacks of step `st` (marked at the end of its run())."""
+        if self.early_prep:
+            for s in self.sides:
+                s.wait_mark(self.ctx, self.CONV_DONE_MARK + st['cur'])
+                s.wait_mark(self.img_ctx, self.CONV_DONE_MARK + st['cur'])
 
     def _tail(self, st):
         """Stages after the extractors for every frame of step `st` (a11-a14)."""

@@ -55,6 +55,9 @@ int dodt_ctx_sync(dodt_ctx* ctx);
 /* Timing marks (256 per context) for stream-level timelines: record one on ctx's stream;
  * elapsed GPU time between two marks, possibly of different contexts (waits for `to`). */
 int dodt_mark(dodt_ctx* ctx, int slot);
+/* Later work on ctx waits for mark `slot` of `other` as last recorded (dodt_ctx_wait_for with the point of
+ * `other`'s stream chosen earlier than the call). */
+int dodt_ctx_wait_mark(dodt_ctx* ctx, dodt_ctx* other, int slot);
 int dodt_mark_elapsed(dodt_ctx* from, int from_slot, dodt_ctx* to, int to_slot, float* ms);
 /* Stream-level join: work enqueued on ctx AFTER this call starts only when
  * everything enqueued on `other` BEFORE this call has finished (hipEventRecord on
