@@ -393,9 +393,28 @@ class FramePairPipeline(object):
             return
         if self.on_records_reuse is not None:
             self.on_records_reuse(st['rslot'], self.sides)
-        for f in range(nf):
+        computed = heads is None
+        # The T branch of a pair hangs on frame 0's tail, which makes it half as long again as frame 1's.  Its map
+        # and crops (not the head) therefore go onto frame 1's stream, between that frame's own crops and head:
+        # frame 0's stream marks the point where its proposals stand (slot PROPOSALS_MARK), frame 1's waits for it,
+        # correlates, crops and marks CORR_ROIS_MARK, which frame 0's stream waits for in front of the correlation
+        # head.  The frames' launches are enqueued in that order: frame 0 up to its head, frame 1 whole, frame
+        # 0's rest (DODT_PIPE_CORR_ON_F1=0: all of the branch on frame 0's stream).
+        split_t = computed and self.fps == 2 and ns >= 2 and not os.environ.get('DODT_PIPE_NO_CORR') \
+            and os.environ.get('DODT_PIPE_CORR_ON_F1', '1') != '0'
+
+        def t_branch_crops(cc, f0, scratch):
+            """Correlation map of pair (f0, f0 + 1) and its 7x7 crops at frame f0's proposals, on context cc."""
+            fb0 = feat['bev_feat'].offset(4 * bev_px * FC * f0, bev_hw + (FC,))
+            fb1 = feat['bev_feat'].offset(4 * bev_px * FC * (f0 + 1), bev_hw + (FC,))
+            ops.correlation(cc, fb0, fb1, bev_hw + (FC,), CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD,
+                            scratch['corr_map'])
+            ops.crop_and_resize(cc, scratch['corr_map'], bev_hw + (CORR_CH,), fr[f0]['top_bev'], self.P,
+                                fr[f0]['top_count'], (ROI, ROI), fr[f0]['corr_rois'],
+                                out_box_stride=self.corr_head.in_ld)
+
+        def frame(f):
             c, b, A = self.sides[f % ns], fr[f], counts[f]
-            computed = heads is None
             h = b if computed else heads[f]
             scratch = self.head_scratch[f % ns] if computed else None
             self._mark(c, st['step'], 'tail%d_start' % f)
@@ -431,6 +450,7 @@ class FramePairPipeline(object):
                                 b['top_count'], (ROI, ROI), b['bev_rois'])
             ops.crop_and_resize(c, feat_i, img_hw + (FC,), b['top_img'], self.P,
                                 b['top_count'], (ROI, ROI), b['img_rois'])
+            yield 'crops'
             pair = self.fps == 2
             corr_offsets = h.get('corr_offsets') if pair and f % 2 == 0 else None
             self._mark(c, st['step'], 'tail%d_crops2' % f)
@@ -440,15 +460,14 @@ class FramePairPipeline(object):
                                        + ([b['angle_vectors']] if self.box_4ca else []),
                                        scratch['fc'])
                 self._mark(c, st['step'], 'tail%d_fc2' % f)
+                yield 'head'
                 if pair and f % 2 == 0 and not os.environ.get('DODT_PIPE_NO_CORR'):
                     # T branch: correlate the pair's BEV features, crop with frame 0's
                     # proposals (dt_rpn_model.py:324-331, dt_avod_model.py:267-273,300-304)
-                    feat_b1 = feat['bev_feat'].offset(4 * bev_px * FC * (f + 1), bev_hw + (FC,))
-                    ops.correlation(c, feat_b, feat_b1, bev_hw + (FC,),
-                                    CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD, scratch['corr_map'])
-                    ops.crop_and_resize(c, scratch['corr_map'], bev_hw + (CORR_CH,),
-                                        b['top_bev'], self.P, b['top_count'], (ROI, ROI),
-                                        b['corr_rois'], out_box_stride=self.corr_head.in_ld)
+                    if split_t:
+                        c.wait_mark(self.sides[(f + 1) % ns], self.CORR_ROIS_MARK)
+                    else:
+                        t_branch_crops(c, f, scratch)
                     self._mark(c, st['step'], 'tail%d_corrmap' % f)
                     self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
                                            [b['corr_offsets']], scratch['fc'])
@@ -475,6 +494,32 @@ class FramePairPipeline(object):
                 self.d_rec_counts.offset(4 * f, (1,), np.int32), d_corr_offsets=corr_offsets,
                 d_orientations=b['orientations'] if self.box_4ca else None)
             self._mark(c, st['step'], 'tail%d_end' % f)
+
+        def drain(g):
+            for _ in g:
+                pass
+
+        if not split_t:
+            for f in range(nf):
+                drain(frame(f))
+            return
+        for f0 in range(0, nf, 2):
+            c0, c1 = self.sides[f0 % ns], self.sides[(f0 + 1) % ns]
+            g0, g1 = frame(f0), frame(f0 + 1)
+            while next(g0) != 'crops':          # frame 0 up to its 7x7 crops: its proposals stand
+                pass
+            c0.mark(self.PROPOSALS_MARK)
+            while next(g0) != 'head':           # ... and its stage-2 head
+                pass
+            while next(g1) != 'crops':          # frame 1 up to its crops, then the T branch's map and crops
+                pass
+            c1.wait_mark(c0, self.PROPOSALS_MARK)
+            t_branch_crops(c1, f0, self.head_scratch[(f0 + 1) % ns])
+            c1.mark(self.CORR_ROIS_MARK)
+            drain(g1)
+            drain(g0)                           # waits for CORR_ROIS_MARK: correlation head, NMS #2, records
+
+    PROPOSALS_MARK, CORR_ROIS_MARK = 252, 253   # mark slots of the side contexts (the T branch's hand-overs)
 
     def sync(self):
         self.ctx.sync()
