@@ -822,7 +822,16 @@ int dodt_fc_forward(dodt_fc* f, dodt_ctx* ctx, const float* d_x, const float* d_
         return launch_fc_skinny(s, a, so, f->bf16);
     }
     if (f->bf16) {
-        if (f->BN == 128) return launch_fc<64, 128, 2, 2, 128, 128, true>(s, a, f->Npad);
+        if (f->BN == 128) {
+            // Stage depth (DODT_FC_BF16_BK).  128 k is the fastest layer alone (343 TFLOP/s at M = 1024, N = K = 2048;
+            // 64: 320, 32: 264) but its two 50 KB buffers leave room for one workgroup per CU and none beside a conv
+            // workgroup; in the frame-pair pipeline, where the heads' GEMMs run in what two resident conv workgroups leave
+            // of a CU (42 KB of LDS, 224 registers), 32 k (27 KB) wins: 802 -> 823 pairs/s with bf16 convs and heads.
+            static const int bk = getenv("DODT_FC_BF16_BK") ? atoi(getenv("DODT_FC_BF16_BK")) : 32;
+            if (bk == 64) return launch_fc<64, 128, 2, 2, 128, 64, true>(s, a, f->Npad);
+            if (bk == 32) return launch_fc<64, 128, 2, 2, 128, 32, true>(s, a, f->Npad);
+            return launch_fc<64, 128, 2, 2, 128, 128, true>(s, a, f->Npad);
+        }
         return launch_fc<128, 32, 4, 1, 32, 64, true>(s, a, f->Npad);
     }
     if (f->BN == 128) {
