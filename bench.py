@@ -228,6 +228,19 @@ def main():
     except _lib.DodtError as e:
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path (%s)' % e)
     comm, host_sync, comm_error = None, None, None
+    if world > 1:
+        # A rank that never reaches the communicator's set-up would leave the others in ncclCommInitRank for
+        # good: a watchdog ends this rank instead (the launcher then ends the job) -- cancelled once the ranks
+        # have met in their first barrier.
+        import signal
+
+        def _stuck(signum, frame):
+            sys.stderr.write('[bench] rank %d: the ranks did not meet within 600 s (RCCL set-up or the first '
+                             'barrier); giving up\n' % rank)
+            sys.stderr.flush()
+            os._exit(3)
+        signal.signal(signal.SIGALRM, _stuck)
+        signal.alarm(600)
     if world > 1 or args.comm:
         try:
             comm = sharding.Communicator(ctx, rank, world)
@@ -334,6 +347,8 @@ def main():
                 comm.barrier()          # drains the side stream, then all ranks meet
             elif host_sync is not None:
                 host_sync.barrier()
+            if world > 1:
+                signal.alarm(0)         # the ranks have met: the set-up watchdog retires
 
         # steps are pipelined two deep inside pipe.run(); finish() drains the last one, so
         # exactly `steps` complete steps (convs AND tails) lie inside the timed region
