@@ -243,7 +243,18 @@ def main():
         signal.alarm(600)
     if world > 1 or args.comm:
         try:
-            comm = sharding.Communicator(ctx, rank, world)
+            # librccl prints a version banner on stdout when it starts: the job's stdout is ONE JSON line, so the
+            # process's fd 1 points at stderr while the communicator is made
+            sys.stdout.flush()
+            saved_out = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                comm = sharding.Communicator(ctx, rank, world)
+                comm.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_out, 1)
+                os.close(saved_out)
         except Exception as e:      # RCCL missing or the ranks could not meet
             if world == 1:
                 raise
@@ -313,6 +324,9 @@ def main():
             batches.append(b)
 
         state = {'sent': 0, 'last_block': None}     # steps whose records have been shipped
+        if comm is not None and os.environ.get('DODT_BENCH_COMM_STREAM', 'side') == 'side':
+            # the exchange on frame 1's side stream instead of a fifth stream (DODT_BENCH_COMM_STREAM=own)
+            comm.attach(pipe.sides[-1])
 
         def gather_block(b):
             # on the communicator's side stream, behind what the main stream holds so far (the

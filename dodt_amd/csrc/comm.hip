@@ -89,6 +89,7 @@ struct dodt_comm {
     int device = 0, rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;          // the side stream every collective runs on
+    bool owns_stream = true;               // false once attached to a context's stream (dodt_comm_attach)
     hipEvent_t produced = nullptr;         // recorded on the producer's stream
     hipEvent_t done[kSlots] = {};          // gather of slot s has left the side stream
     bool used[kSlots] = {};
@@ -147,8 +148,18 @@ int dodt_comm_destroy(dodt_comm* c) {
     if (c->produced) (void)hipEventDestroy(c->produced);
     for (int i = 0; i < kSlots; ++i)
         if (c->done[i]) (void)hipEventDestroy(c->done[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return DODT_OK;
+}
+
+int dodt_comm_attach(dodt_comm* c, dodt_ctx* ctx) {
+    DODT_REQUIRE(c && ctx, "dodt_comm_attach: NULL argument");
+    DODT_REQUIRE(ctx->device == c->device, "dodt_comm_attach: context of another device");
+    DODT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = ctx->stream;
+    c->owns_stream = false;
     return DODT_OK;
 }
 

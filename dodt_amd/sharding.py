@@ -88,6 +88,10 @@ class Communicator(object):
             self.handle, producer.handle, int(slot), d_rec.ptr, d_cnt.ptr, pairs, frames, max_det,
             cols, d_all_rec.ptr, d_all_cnt.ptr), 'dodt_all_gather_records')
 
+    def attach(self, ctx):
+        """Run the collectives on ctx's stream from now on (no stream of the communicator's own)."""
+        self._lib.check(self.lib.dodt_comm_attach(self.handle, ctx.handle), 'dodt_comm_attach')
+
     def join(self, slot, consumer):
         """`consumer`'s later work waits for the gather last enqueued with `slot`."""
         self._lib.check(self.lib.dodt_comm_join(self.handle, int(slot), consumer.handle),

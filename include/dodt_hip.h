@@ -434,6 +434,10 @@ typedef struct dodt_comm dodt_comm;
 int dodt_comm_unique_id(uint8_t* id_out);
 int dodt_comm_create(dodt_ctx* ctx, int rank, int world, const uint8_t* id, dodt_comm** out);
 int dodt_comm_destroy(dodt_comm* comm);
+/* From now on the communicator's collectives run on ctx's stream instead of a stream of their own (every stream
+ * beyond four costs this runtime throughput): they then sit in that stream's order, between the
+ * caller's kernels.  ctx must outlive the communicator. */
+int dodt_comm_attach(dodt_comm* comm, dodt_ctx* ctx);
 int dodt_comm_rank(const dodt_comm* comm, int* rank, int* world);
 int dodt_all_gather_records(dodt_comm* comm, dodt_ctx* producer, int slot, const float* d_records,
                             const int32_t* d_counts, int pairs, int frames, int max_det, int cols,

@@ -14,8 +14,11 @@ pytestmark = pytest.mark.gpu
 C = config.PYRAMID_DODT
 
 
-def test_one_rank_communicator_gathers_pipeline_records(tmp_path):
-    """bench.py's pattern: the pipeline writes step k into slot k % 2G of a contiguous ring, a block of
+@pytest.mark.parametrize('attach', [False, True])
+def test_one_rank_communicator_gathers_pipeline_records(tmp_path, attach):
+    """(attach: the collectives on frame 1's side stream instead of a stream of the communicator's own --
+    bench.py's default since a fifth stream costs 2 % of the pairs/s.)
+    bench.py's pattern: the pipeline writes step k into slot k % 2G of a contiguous ring, a block of
     G steps is one grouped all-gather on the side stream, the tail that refills a slot joins the
     gather that last read its block."""
     ctx = device.default_context()
@@ -25,6 +28,8 @@ def test_one_rank_communicator_gathers_pipeline_records(tmp_path):
     rec_ring = ctx.zeros((2 * G, 1, 2, MAX_DET, REC_COLS), np.float32)
     cnt_ring = ctx.zeros((2 * G, 1, 2), np.int32)
     pipe.use_record_ring(rec_ring, cnt_ring)
+    if attach:
+        comm.attach(pipe.sides[-1])
     nr, nc = 4 * 2 * MAX_DET * REC_COLS, 4 * 2
     blocks = [(rec_ring.offset(b * G * nr, (G, 2, MAX_DET, REC_COLS)),
                cnt_ring.offset(b * G * nc, (G, 2), np.int32)) for b in range(2)]
