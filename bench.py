@@ -28,8 +28,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=120000)
     ap.add_argument('--proposals', type=int, default=1024)
     ap.add_argument('--pairs-per-step', type=int, default=1,
