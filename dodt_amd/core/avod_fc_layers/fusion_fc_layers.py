@@ -31,6 +31,10 @@ class EarlyFusionFcLayers(object):
             w0 = np.concatenate([w0, np.zeros((self.in_ld - self.in_k, w0.shape[1]), np.float32)], 0)
         self.hidden = [ops.FullyConnected(ctx, w0 if k == names[0] else params[k]['w'], params[k]['b'],
                                           True, dtype=dtype) for k in names]
+        # for callers that hand over packed (n,h,w,c) crops of a K that is no multiple of 32: the first
+        # layer with its own K (made on first use; it takes the register-staged kernel)
+        self._packed_first = None
+        self._first_params = (params[names[0]]['w'], params[names[0]]['b'], dtype)
         self.outputs = [ops.FullyConnected(ctx, params[k]['w'], params[k]['b'], False, dtype=dtype)
                         for k in outputs]
         # build_output_layers' layers all read fc_drop (fusion_fc_layers.py:94-133): one layer with the
@@ -56,14 +60,23 @@ class EarlyFusionFcLayers(object):
         """d_rois: n rows of `in_ld` floats, the flattened (h,w,c) crop in front and zeros behind it
         (= (n,h,w,c) when in_ld == h*w*c) [and d_rois2, fused by mean]; *d_n rows are valid;
         d_outs: one (n, size) array per output layer."""
-        x, x2, ldx = d_rois, d_rois2, self.in_ld
-        if x2 is not None and len(scratch) > 2 and self.in_ld == self.in_k and self.in_k % 4 == 0:
+        x, x2 = d_rois, d_rois2
+        ldx = self._row_floats(d_rois, n, 'd_rois')
+        if x2 is not None and self._row_floats(x2, n, 'd_rois2') != ldx:
+            raise ValueError('d_rois and d_rois2 must have the same row layout')
+        first = self.hidden[0]
+        if ldx != self.in_ld:          # packed rows of in_k floats, in_k % 32 != 0
+            if self._packed_first is None:
+                w, b, dtype = self._first_params
+                self._packed_first = ops.FullyConnected(self.ctx, w, b, True, dtype=dtype)
+            first = self._packed_first
+        if x2 is not None and len(scratch) > 2 and ldx == self.in_ld == self.in_k and self.in_k % 4 == 0:
             # the mean of the two crops as its own pass (avod_fc_layer_utils.py:38-41: (a + b) / 2,
             # the same float32 arithmetic): fc6 then runs as the plain GEMM, twice as fast as the
             # form that averages inside its K loop
             ops.mean_fusion(ctx, x, x2, n, d_n, self.in_ld, scratch[2])
             x, x2 = scratch[2], None
-        for i, l in enumerate(self.hidden):
+        for i, l in enumerate([first] + self.hidden[1:]):
             y = scratch[i & 1]
             l.forward(x, n, y, ldx=ldx, ldy=self.width, d_x2=x2, d_m=d_n, ctx=ctx)
             x, x2, ldx = y, None, self.width
@@ -73,11 +86,28 @@ class EarlyFusionFcLayers(object):
         for l, d_y in zip(self.outputs, d_outs):
             l.forward(x, n, d_y, ldx=ldx, d_m=d_n, ctx=ctx)
 
+    def _row_floats(self, d, n, name):
+        """Floats per row of a crop block: `in_ld` (zero-tailed rows, what make_scratch / the pipeline
+        allocate) or `in_k` (packed (n,h,w,c) crops); anything else would be read at the wrong offsets
+        and past its end, so it is an error.  The zero tail is the caller's: the crop kernel never writes it."""
+        if d.dtype != np.float32:
+            raise ValueError('%s must be float32' % name)
+        size = int(np.prod(d.shape, dtype=np.int64))
+        rows = d.shape[0] if len(d.shape) > 1 else 0
+        if rows < n or rows == 0 or size % rows:
+            raise ValueError('%s holds %s, fewer than %d rows' % (name, d.shape, n))
+        per_row = size // rows
+        if per_row not in (self.in_ld, self.in_k):
+            raise ValueError('%s rows hold %d floats; the head takes %d (crop + zero tail) or %d (packed)'
+                             % (name, per_row, self.in_ld, self.in_k))
+        return per_row
+
     def flops(self, n):
         """Of the layers as the reference defines them (the zero rows of a padded K do not count)."""
         return sum(l.flops(n) for l in self.hidden + self.outputs) \
             - 2.0 * n * (self.in_ld - self.in_k) * self.hidden[0].N
 
     def close(self):
-        for l in self.hidden + self.outputs + ([self.fused_out] if self.fused_out is not None else []):
-            l.close()
+        for l in self.hidden + self.outputs + [self.fused_out, self._packed_first]:
+            if l is not None:
+                l.close()

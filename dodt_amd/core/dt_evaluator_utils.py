@@ -68,8 +68,89 @@ def base_intersection(box, other):
     return _area(p)
 
 
+def _rects(b):
+    """(m,4,2) base corners of boxes (m,7), the same corner order and arithmetic as _rect."""
+    c, s = np.cos(b[:, 6, None]), np.sin(b[:, 6, None])
+    xc = b[:, 3, None] / 2 * np.array([1, 1, -1, -1])
+    zc = b[:, 4, None] / 2 * np.array([1, -1, -1, 1])
+    return np.stack([c * xc + s * zc + b[:, 0, None], -s * xc + c * zc + b[:, 2, None]], 2)
+
+
+def _clip_batch(poly, cnt, a, b):
+    """_clip for m polygons at once.  poly (m,V,2) with cnt (m,) valid vertices each, edge a->b (m,2) each;
+    returns (m,V+1,2), counts.  Every vertex and every crossing point is computed by the same expressions
+    as in _clip, in the same order, so the polygons are bit-identical to the one-by-one form."""
+    m, V, _ = poly.shape
+    d = b - a
+    side = d[:, 0, None] * (poly[:, :, 1] - a[:, 1, None]) - d[:, 1, None] * (poly[:, :, 0] - a[:, 0, None])
+    idx = np.arange(V)[None, :]
+    valid = idx < cnt[:, None]
+    nxt = np.where(idx + 1 < cnt[:, None], idx + 1, 0)
+    pj = np.take_along_axis(poly, nxt[:, :, None], 1)
+    sj = np.take_along_axis(side, nxt, 1)
+    keep = valid & (side >= 0)
+    cross = valid & ((side >= 0) != (sj >= 0))
+    with np.errstate(divide='ignore', invalid='ignore'):      # slots that are not crossings are not read
+        t = side / (side - sj)
+        inter = poly + t[:, :, None] * (pj - poly)
+    emit = keep.astype(np.intp) + cross
+    first = np.cumsum(emit, 1) - emit
+    out = np.zeros((m, V + 1, 2))
+    r, v = np.nonzero(keep)
+    out[r, first[r, v]] = poly[r, v]
+    r, v = np.nonzero(cross)
+    out[r, first[r, v] + keep[r, v]] = inter[r, v]
+    return out, emit.sum(1)
+
+
+def base_intersections(boxes_a, boxes_b):
+    """Exact overlap areas of the bases of boxes_a[i] and boxes_b[i] (m,7 each): the Sutherland-Hodgman
+    clipping of base_intersection, all m pairs per numpy call."""
+    p, q = _rects(boxes_a), _rects(boxes_b)
+    e0, e1 = q[:, 1] - q[:, 0], q[:, 2] - q[:, 1]
+    flip = e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0] < 0
+    q[flip] = q[flip, ::-1]
+    cnt = np.full(len(p), 4, np.intp)
+    for i in range(4):
+        p, cnt = _clip_batch(p, cnt, q[:, i], q[:, (i + 1) % 4])
+    # shoelace over the valid vertices: the slots behind them repeat vertex 0, which adds exact zeros
+    idx = np.arange(p.shape[1])[None, :]
+    p = np.where((idx < cnt[:, None])[:, :, None], p, p[:, :1])
+    x, z = p[:, :, 0], p[:, :, 1]
+    area = 0.5 * np.abs((x * np.roll(z, -1, 1)).sum(1) - (z * np.roll(x, -1, 1)).sum(1))
+    return np.where(cnt >= 3, area, 0.0)
+
+
+def three_d_iou_matrix(boxes_a, boxes_b):
+    """(na,nb) 3-D IoU of every box of boxes_a (na,7) with every box of boxes_b (nb,7), [x,y,z,l,w,h,ry]
+    (y = bottom, down positive).  Pairs whose bounding spheres do not touch are 0 without clipping (the
+    reference's own early exit, wavedata/.../evaluation.py:60-75); the others are clipped in one batch."""
+    a = np.atleast_2d(np.asarray(boxes_a, dtype=np.float64))
+    b = np.atleast_2d(np.asarray(boxes_b, dtype=np.float64))
+    iou = np.zeros((len(a), len(b)))
+    if iou.size == 0:
+        return iou
+    diag_a = np.sqrt((a[:, 3:6] ** 2).sum(1)) / 2
+    diag_b = np.sqrt((b[:, 3:6] ** 2).sum(1)) / 2
+    dist = np.sqrt(((b[None, :, 0:3] - a[:, None, 0:3]) ** 2).sum(2))
+    i, j = np.nonzero(diag_a[:, None] + diag_b[None, :] >= dist)
+    if len(i) == 0:
+        return iou
+    ba, bb = a[i], b[j]
+    h_int = np.maximum(0.0, np.minimum(ba[:, 1], bb[:, 1]) - np.maximum(ba[:, 1] - ba[:, 5], bb[:, 1] - bb[:, 5]))
+    inter = h_int * base_intersections(ba, bb)
+    iou[i, j] = inter / (np.prod(ba[:, 3:6], 1) + np.prod(bb[:, 3:6], 1) - inter)
+    return iou
+
+
 def three_d_iou(box, boxes):
     """box (7,), boxes (n,7), both [x,y,z,l,w,h,ry] (y = bottom, down positive) -> (n,) IoU."""
+    return three_d_iou_matrix(np.asarray(box, dtype=np.float64)[None], boxes)[0]
+
+
+def three_d_iou_one_by_one(box, boxes):
+    """The same IoU with the bases clipped pair by pair in Python (base_intersection): what three_d_iou was
+    before it was batched; kept as the cross-check of the batched form (tests/test_temporal.py)."""
     boxes = np.atleast_2d(np.asarray(boxes, dtype=np.float64))
     box = np.asarray(box, dtype=np.float64)
     diag = np.sqrt((box[3:6] ** 2).sum()) / 2
@@ -127,10 +208,16 @@ def _fill(track_a, track_b, num):
     return out
 
 
-def interpolate_non_keyframe_predictions(predictions, n_frames, threshold, recover=None):
+def interpolate_non_keyframe_predictions(predictions, n_frames, threshold, recover=None, on_conflict='raise'):
     """predictions (n,17): box_3d(7), score, type, shifted box(7), frame mark (0/1).
     n_frames: frames from keyframe 0 to keyframe 1 inclusive (tau + 1; 1 = a lone frame).
-    Returns n_frames arrays (k,13), like the reference (columns [:-4] of the records)."""
+    Returns n_frames arrays (k,13), like the reference (columns [:-4] of the records).
+    on_conflict: two keyframe-0 detections whose best match is the same keyframe-1 detection make the
+    reference raise ValueError (`next_idx.remove`, dt_evaluator_utils.py:266-268) -- 'raise', the default,
+    does the same; 'next_best' gives the later one its best still-free match instead (IoU > 0, else none),
+    for callers that must not stop on such a pair."""
+    if on_conflict not in ('raise', 'next_best'):
+        raise ValueError("on_conflict must be 'raise' or 'next_best'")
     p = np.asarray(predictions, dtype=np.float64).reshape(-1, 17)
     rec = recover or (lambda i, rows: rows)
     kept = [p[(p[:, -1] == i) & (p[:, 7] > threshold)] for i in range(min(n_frames, 2))]
@@ -146,11 +233,16 @@ def interpolate_non_keyframe_predictions(predictions, n_frames, threshold, recov
         pairs = [(None, o) for o in k1]
     else:
         free = list(range(len(k1)))
-        for cur in k0:
+        # every keyframe-0 detection against all of frame 1 (as the reference: not only the free ones),
+        # all of them in one batch
+        iou_all = three_d_iou_matrix(k0[:, :7], k1[:, :7]) if len(k1) else None
+        for n, cur in enumerate(k0):
             match = None
             if free:
-                ious = three_d_iou(cur[:7], k1[:, :7])     # over all of frame 1, as the reference
+                ious = iou_all[n]
                 best = int(np.argmax(ious))
+                if ious[best] > 0 and best not in free and on_conflict == 'next_best':
+                    best = free[int(np.argmax(ious[free]))]
                 if ious[best] > 0:
                     match = k1[best]
                     free.remove(best)
@@ -165,16 +257,25 @@ def interpolate_non_keyframe_predictions(predictions, n_frames, threshold, recov
     return [out[0]] + [rec(i, out[i]) for i in range(1, n_frames)]
 
 
-def _iou_3d_kitti(box3d_1, box3d_2):
-    """iou_3d of track_through_ious (dt_evaluator_utils.py:439-447) on KITTI-ordered boxes
+def _kitti_rows(boxes):
+    """iou_3d of track_through_ious (dt_evaluator_utils.py:439-447) takes KITTI-ordered boxes
     [h, w, l, x, y, z, ry].  The reference builds its [ry, l, h, w, tx, ty, tz] rows with the
     index list [-2, 0, 2, 1, 3, 4, 5]: the angle slot receives z, the l slot h and the h slot
-    l -- reproduced as written."""
-    def conv(b):
-        b = np.asarray(b, dtype=np.float64)
-        # reference slots: ry = b[-2], l = b[0], h = b[2], w = b[1], t = b[3:6]
-        return np.array([b[3], b[4], b[5], b[0], b[1], b[2], b[-2]])
-    return float(three_d_iou(conv(box3d_1), conv(box3d_2)[None])[0])
+    l -- reproduced as written.  Returns the rows as [x, y, z, l, w, h, ry] for three_d_iou."""
+    b = np.atleast_2d(np.asarray(boxes, dtype=np.float64))
+    # reference slots: ry = b[-2], l = b[0], h = b[2], w = b[1], t = b[3:6]
+    return b[:, [3, 4, 5, 0, 1, 2, -2]]
+
+
+def _iou_3d_kitti(box3d_1, box3d_2):
+    return float(three_d_iou_matrix(_kitti_rows(box3d_1), _kitti_rows(box3d_2))[0, 0])
+
+
+def _iou_3d_kitti_many(box3d, boxes3d):
+    """One box against a list of boxes: the values of [_iou_3d_kitti(box3d, b) for b in boxes3d], one batch."""
+    if len(boxes3d) == 0:
+        return np.zeros(0)
+    return three_d_iou_matrix(_kitti_rows(box3d), _kitti_rows(np.stack([np.asarray(b, np.float64) for b in boxes3d])))[0]
 
 
 def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_threshold, t_min):
@@ -190,7 +291,8 @@ def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_thresh
     def merge_dets(dets, dets_iou):
         merged = dets
         for item1 in dets_iou:
-            if not any(_iou_3d_kitti(item1['boxes3d'], item2['boxes3d']) > 0 for item2 in dets):
+            # `dets` grows while this loop runs (merged IS dets, as in the reference): one batch per item
+            if not (_iou_3d_kitti_many(item1['boxes3d'], [item2['boxes3d'] for item2 in dets]) > 0).any():
                 item1['offsets'] = item1['boxes3d']
                 merged.append(item1)
         return merged
@@ -205,8 +307,7 @@ def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_thresh
                     merged = merge_dets(dets, dets_iou)
                     dets = copy.deepcopy(merged)
                     dets_iou = copy.deepcopy(merged)
-                ious = [_iou_3d_kitti(track['trajectory'][-1]['offsets'], x['boxes3d'])
-                        for x in dets_iou]
+                ious = _iou_3d_kitti_many(track['trajectory'][-1]['offsets'], [x['boxes3d'] for x in dets_iou])
                 best = int(np.argmax(ious))
                 if ious[best] > iou_threshold:
                     track['trajectory'].append(dets[best])

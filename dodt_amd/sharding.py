@@ -47,33 +47,34 @@ class Communicator(object):
     id, so that concurrent jobs on one host do not meet)."""
 
     SLOTS = 4
+    _generation = {}      # rendezvous base path -> communicators made so far by this process
 
     def __init__(self, ctx, rank, world, id_path=None, timeout_s=120.0):
         from dodt_amd import _lib
         self._lib, self.lib, self.ctx = _lib, ctx.lib, ctx
         self.rank, self.world = int(rank), int(world)
         uid = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-        path = id_path or rendezvous_path()
+        # one file per communicator of a job: the n-th Communicator of every rank meets at `<path>.<n>`
+        base = id_path or rendezvous_path()
+        gen = Communicator._generation.get(base, 0)
+        Communicator._generation[base] = gen + 1
+        path = '%s.%d' % (base, gen)
         if self.rank == 0:
             _lib.check(self.lib.dodt_comm_unique_id(uid), 'dodt_comm_unique_id')
             if self.world > 1:
-                tmp = '%s.%d.tmp' % (path, os.getpid())
-                with open(tmp, 'wb') as fh:
-                    fh.write(bytes(uid))
-                os.replace(tmp, path)
+                publish_id(path, bytes(uid))
         else:
-            t0 = time.time()
-            while not (os.path.exists(path) and os.path.getsize(path) == _lib.COMM_ID_BYTES):
-                if time.time() - t0 > timeout_s:
-                    raise _lib.DodtError('rank %d: no RCCL id at %s after %.0f s'
-                                         % (self.rank, path, timeout_s))
-                time.sleep(0.01)
-            uid = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(open(path, 'rb').read())
+            uid = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(
+                fetch_id(path, _lib.COMM_ID_BYTES, timeout_s, 'rank %d' % self.rank))
         h = C.c_void_p()
-        _lib.check(self.lib.dodt_comm_create(ctx.handle, self.rank, self.world, uid, C.byref(h)),
-                   'dodt_comm_create')
+        try:
+            _lib.check(self.lib.dodt_comm_create(ctx.handle, self.rank, self.world, uid, C.byref(h)),
+                       'dodt_comm_create')
+        finally:
+            # ncclCommInitRank returns once every rank has joined, i.e. has read the id: the file goes now
+            if self.rank == 0 and self.world > 1:
+                _remove(path)
         self.handle = h
-        self._id_path = path if (self.rank == 0 and self.world > 1) else None
 
     def all_gather_records(self, producer, slot, d_rec, d_cnt, d_all_rec, d_all_cnt):
         """Enqueue the step's exchange on the communicator's side stream, behind what
@@ -112,11 +113,47 @@ class Communicator(object):
         if self.handle:
             self.lib.dodt_comm_destroy(self.handle)
             self.handle = None
-        if self._id_path:
-            try:
-                os.remove(self._id_path)
-            except OSError:
-                pass
+
+
+def _remove(path):
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+
+
+def publish_id(path, payload):
+    """Rank 0's half of the id hand-over: the bytes appear at `path` atomically, in a file only this user can
+    read, created exclusively (a file or symlink somebody else put at the temporary name is an error, not a
+    target)."""
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    _remove(tmp)
+    fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_WRONLY | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+    try:
+        os.write(fd, payload)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def fetch_id(path, nbytes, timeout_s=120.0, who='rank'):
+    """The other ranks' half: poll for a regular file of exactly `nbytes` owned by this user."""
+    from dodt_amd import _lib
+    t0 = time.time()
+    while True:
+        try:
+            st = os.lstat(path)
+            import stat
+            if stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_size == nbytes:
+                with open(path, 'rb') as fh:
+                    data = fh.read()
+                if len(data) == nbytes:
+                    return data
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise _lib.DodtError('%s: no RCCL id at %s after %.0f s' % (who, path, timeout_s))
+        time.sleep(0.01)
 
 
 class HostBarrier(object):

@@ -73,7 +73,11 @@ def test_correlation_full_size_properties(ctx):
     # the vector-ALU kernel of layers with K <= 16 (the RPN's 9 -> 512): no fusion, K = 16, no ReLU
     (5500, 9, 512, True, False), (37, 16, 64, False, True), (1, 4, 128, False, False),
     # the LDS-DMA staged kernel (K % 32 == 0, 128-wide blocking): ragged M, two-stage K, fusion
-    (1000, 2048, 2048, True, False), (130, 64, 128, False, False), (513, 96, 256, True, True)])
+    (1000, 2048, 2048, True, False), (130, 64, 128, False, False), (513, 96, 256, True, True),
+    # from ceil(M/64) * (N/128) >= 512 on, the same kernel with 64 x 128 tiles (fc_dma_kernel<false, 2>:
+    # BASELINE.json configs[4], 4096 proposals); with the mean fused the 64 x 64 form stays at any M
+    (4096, 2048, 2048, True, False), (2048, 1248, 2048, True, False), (2100, 2048, 2048, False, False),
+    (2048, 1568, 2048, True, True)])
 def test_fully_connected_matches_oracle(ctx, M, K, N, relu, fuse):
     rng = np.random.default_rng(M + K + N)
     x = rng.normal(size=(M, K)).astype(np.float32)
@@ -168,9 +172,53 @@ def test_fully_connected_split_outputs(ctx, M, K, widths, ldx, rows):
     wide.close()
 
 
+def test_early_fusion_head_checks_row_layout_and_takes_packed_crops(ctx):
+    """EarlyFusionFcLayers.forward strides its input by `in_ld` (K rounded up to 32).  A caller of this
+    avod.core-shaped class that hands over packed (n,7,7,25) crops gets the same result through the layer with
+    its own K; any other row length is an error instead of a read at the wrong offsets."""
+    from dodt_amd.core.avod_fc_layers.fusion_fc_layers import EarlyFusionFcLayers
+    hp = synth.head_params(fc_sizes=(256, 128, 128))
+    head = EarlyFusionFcLayers(ctx, hp['corr'], outputs=('off_out',))
+    assert (head.in_k, head.in_ld) == (7 * 7 * CORR_CH, 1248)
+    n = 77
+    rng = np.random.default_rng(3)
+    rois = rng.normal(size=(n, 7, 7, CORR_CH)).astype(np.float32)
+    want = oheads.corr_fc_early(rois, hp['corr'])
+    scratch = head.make_scratch(n)
+    d_n = ctx.array(np.array([n], np.int32))
+    padded = np.zeros((n, head.in_ld), np.float32)
+    padded[:, :head.in_k] = rois.reshape(n, -1)
+    for d_x in (ctx.array(padded), ctx.array(rois)):           # zero-tailed rows | packed crops
+        d_y = ctx.array(np.full((n, 3), np.nan, np.float32))
+        head.forward(ctx, d_x, None, n, d_n, [d_y], scratch)
+        _close(d_y.download(), want)
+    d_y = ctx.empty((n, 3), np.float32)
+    with pytest.raises(ValueError):
+        head.forward(ctx, ctx.array(rois[:, :, :, :24]), None, n, d_n, [d_y], scratch)
+    with pytest.raises(ValueError):
+        head.forward(ctx, ctx.array(rois[:10]), None, n, d_n, [d_y], scratch)        # too few rows
+    with pytest.raises(ValueError):
+        head.forward(ctx, ctx.array(padded), ctx.array(rois), n, d_n, [d_y], scratch)   # mixed layouts
+    head.close()
+
+
 @pytest.mark.parametrize('conv_dtype,head_dtype', [('f32', 'f32'), ('f32s', 'f32'),
                                                    ('bf16', 'bf16')])
 def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head_dtype):
+    _stagewise(ctx, conv_dtype, head_dtype, seq=4, frames=(0, 2), n_points=None, proposals=1024)
+
+
+def test_dense_scene_with_computed_heads_matches_oracle_stagewise(ctx):
+    """BASELINE.json configs[4]'s shape with the heads COMPUTED (S + T): 300k points per frame, tau = 3,
+    4096 proposals.  At M = 4096 the 2048-wide layers of the stage-2 and correlation heads take
+    fc_dma_kernel's 64 x 128-tile form (gemm.hip: launch_fc_dma), the correlation crops, the padded-K
+    correlation head, mean_fusion and the split output layers run at P = 4096 -- same protocol and bars
+    as the 1024-proposal test (fusion_fc_layers.py:136-180, dt_avod_model.py:253-273)."""
+    n_top = _stagewise(ctx, 'f32', 'f32', seq=9, frames=(0, 3), n_points=300000, proposals=4096)
+    assert min(n_top) > 2048, n_top       # enough rows for the 64 x 128 form: ceil(M/64) * 16 >= 512
+
+
+def _stagewise(ctx, conv_dtype, head_dtype, seq, frames, n_points, proposals):
     """Heads computed on the device.  Every dense stage is checked against the oracle on the
     inputs the device produced for it; the index stages downstream are then checked exactly,
     the oracle consuming the device's own logits (a logit differing in the last bits may
@@ -182,11 +230,13 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
     # boundary may round the other way (1 ulp = 2^-8 of that element) and shift the next
     # layer's outputs; after four layers up to ~2e-3 of the output scale
     tol = 1e-4 if head_dtype == 'f32' else 5e-3
-    pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=1024, head_params=hp, conv_dtype=conv_dtype,
-                             head_dtype=head_dtype)
-    frames = (0, 2)
-    pts = [synth.lidar_frame(4, f) for f in frames]
-    imgs = [synth.image_frame(4, f) for f in frames]
+    kw = {} if n_points is None else dict(n_points_max=n_points)
+    pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=proposals, head_params=hp,
+                             conv_dtype=conv_dtype, head_dtype=head_dtype, **kw)
+    pkw = {} if n_points is None else dict(n_points=n_points, n_boxes=40)     # 40 boxes in the dense scene
+    pts = [synth.lidar_frame(seq, f, **pkw) for f in frames]
+    imgs = [synth.image_frame(seq, f) for f in frames]
+    n_tops = []
     cur = pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts],
                    [ctx.array(i) for i in imgs])
     pipe.finish()
@@ -209,6 +259,7 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
         _close(heads['rpn_offsets'], off, tol)
         n_top = int(b['top_count'].download()[0])
         assert n_top > 100
+        n_tops.append(n_top)
         # stage-2 heads on the device's crops
         cls, o4c, ang = oheads.fusion_fc_early(b['bev_rois'].download()[:n_top],
                                                b['img_rois'].download()[:n_top], hp['avod'],
@@ -252,6 +303,7 @@ def test_pair_with_computed_heads_matches_oracle_stagewise(ctx, conv_dtype, head
     with pytest.raises(ValueError):
         pipe.run([], [], [], heads=[{}])
     pipe.close()
+    return n_tops
 
 
 FREE_RUNNING_MODES = (('direct', '0'), ('F(2x2,3x3)', '2'), ('F(4x4,3x3)', '4'))
