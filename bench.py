@@ -57,6 +57,17 @@ def parse():
                          'step on a single GPU)')
     ap.add_argument('--cpu-pairs', type=int, default=2,
                     help='frame pairs (= pool workers) of the CPU baseline sample')
+    ap.add_argument('--tau', type=int, default=2, help='frame stride of a pair (frames f, f + tau)')
+    ap.add_argument('--boxes', type=int, default=12,
+                    help='car-sized boxes in a synthetic cloud (SURVEY 8d: 12; 40 in the dense scene)')
+    ap.add_argument('--sustained-steps', type=int, default=2000,
+                    help='steps of alt.sustained, the headline workload over seconds (0: skip)')
+    ap.add_argument('--allow-no-exchange', action='store_true',
+                    help='N > 1 only: when RCCL cannot make the communicator, still time the ranks (host barrier, '
+                         'NO records exchanged, said in config.exchange) instead of leaving with an error')
+    ap.add_argument('--late-peer-ms', type=float, default=0.0,
+                    help='experiment (with --comm): a device-side delay of this many ms in front of every gather on '
+                         "the stream that carries the collectives -- a peer that arrives late at the rendezvous")
     return ap.parse_args()
 
 
@@ -161,14 +172,63 @@ def cpu_baseline(computed_heads=True, pairs=2):
                             'pool_workers': cores, 'unit': 'frames/s'})
 
 
+def _temporal_worker(job):
+    """The host's temporal module ("M" of S+T+M) over one synthetic sequence on ONE thread: per pair the
+    association + interpolation of the non-keyframes (interpolate_non_keyframe_predictions), then the
+    sequence's tracker (encode_tracking_dets + track_through_ious with the reference's thresholds,
+    avod_stack_tracking.config:137-140).  job: (records of the sequence's pairs, tau, repeats); returns
+    seconds per repeat and the number of tracks."""
+    records, tau, repeats = job
+    if records is None:
+        import dodt_amd.core.dt_evaluator_utils  # noqa: F401  (warm-up: spawn + imports)
+        import dodt_amd.core.dt_inference_utils  # noqa: F401
+        return 0.0, 0
+    from threadpoolctl import threadpool_limits
+    from dodt_amd import synth
+    from dodt_amd.core import dt_evaluator_utils as M
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            for rec in records:
+                M.interpolate_non_keyframe_predictions(rec, tau + 1, 0.1, on_conflict='next_best')
+            dt, di = M.encode_tracking_dets([(k * tau, k * tau + tau, rec) for k, rec in enumerate(records)],
+                                            synth.P2, synth.IMAGE_WH, ['Car'], 0.1)
+            tracks = M.track_through_ious(dt, di, 0.5, 0.005, 3)
+        return (time.perf_counter() - t0) / repeats, len(tracks)
+
+
+def temporal_host(pool, cores, records, tau, gpu_pairs_per_s):
+    """alt.temporal_host: pairs/s of the host temporal module on the records the timed steps produced."""
+    n_det = float(np.mean([len(r) for r in records])) / 2.0
+    one, n_tracks = _temporal_worker((records, tau, 3))
+    res = dict(stage='M of S+T+M on the host: interpolate_non_keyframe_predictions per pair + encode_tracking_dets + '
+                     'track_through_ious per sequence (dodt_amd/core/dt_evaluator_utils.py; reference '
+                     'dt_evaluator_utils.py:212-296,368-511)',
+               records='%d consecutive steps of the timed run as one sequence, %.0f detections per frame on average, '
+                       'tau = %d; %d tracks' % (len(records), n_det, tau, n_tracks),
+               one_thread_pairs_per_s=round(len(records) / one, 1), ms_per_pair_one_thread=round(one / len(records) * 1e3, 3),
+               unit='frame-pairs/s')
+    if pool is not None:
+        t0 = time.perf_counter()
+        out = pool.map(_temporal_worker, [(records, tau, 6)] * cores)
+        wall = time.perf_counter() - t0
+        res.update(pool_pairs_per_s=round(cores * 6 * len(records) / wall, 1), pool_workers=cores,
+                   pool_note='%d single-thread worker processes, one sequence each (sequences are independent)' % cores)
+        res['keeps_up_with_gpu'] = bool(res['pool_pairs_per_s'] >= gpu_pairs_per_s)
+        res['gpu_pairs_per_s'] = round(gpu_pairs_per_s, 1)
+        res['threads_needed_for_gpu_rate'] = int(np.ceil(gpu_pairs_per_s / max(res['one_thread_pairs_per_s'], 1e-9)))
+    return res
+
+
 FP32_MFMA_PEAK = 157.3     # TFLOP/s dense, MI355X_MICROARCH.md chip table (v_mfma_f32_*_f32)
 BF16_MFMA_PEAK = 2500.0    # TFLOP/s dense
 HBM_PEAK = 8000.0          # GB/s
 
 
 def _spawn_ranks(args):
-    """Started by hand with --gpus N and no launcher: run the ranks as plain child processes
-    (nothing has touched the GPU in this one) and leave with the worst exit code."""
+    """Started by hand with --gpus N and no launcher: run the ranks as plain child processes (nothing has
+    touched the GPU in this one), SUPERVISED: the first rank that leaves with an error ends the others (a rank
+    blocked in an RCCL collective whose peer is gone would otherwise wait for ever), and that code is returned."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -180,7 +240,37 @@ def _spawn_ranks(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DODT_RUN_ID=str(os.getpid()))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env))
-    return max(p.wait() for p in procs)
+    return _supervise(procs)
+
+
+def _supervise(procs, poll_s=0.2, grace_s=10.0):
+    """Wait for child processes; on the first non-zero exit terminate (then kill) the rest.  Returns the first
+    failure's code, else 0."""
+    failed = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and not failed:
+                failed = rc if rc > 0 else 128 - rc
+                sys.stderr.write('[bench] a rank left with code %d: ending the other %d\n' % (rc, len(live)))
+                for q in live:
+                    q.terminate()
+                t_end = time.time() + grace_s
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.0, t_end - time.time()))
+                    except Exception:
+                        q.kill()
+                        q.wait()
+                live = []
+                break
+        if live:
+            time.sleep(poll_s)
+    return failed
 
 
 def _group_by_kernel(layers):
@@ -216,6 +306,13 @@ def main():
         # first, while the GPU is still untouched: the workers are spawned processes
         baseline = cpu_baseline(args.heads == 'computed', args.cpu_pairs)
 
+    m_pool, m_cores = None, _usable_cores()
+    if not args.no_alt and world == 1 and args.config == 'dodt' and args.heads == 'computed':
+        # the temporal module's workers: spawned now, while the GPU is untouched, idle until alt.temporal_host
+        import multiprocessing as mp
+        m_pool = mp.get_context('spawn').Pool(m_cores)
+        m_pool.map(_temporal_worker, [(None, 0, 0)] * m_cores)
+
     from dodt_amd import _lib, config, device, ops, sharding, synth
     from dodt_amd.pipeline import (CORR_CH, CORR_MAX_DISP, CORR_PAD, CORR_STRIDE2, MAX_DET, REC_COLS,
                                    ROI, FramePairPipeline)
@@ -228,19 +325,28 @@ def main():
     except _lib.DodtError as e:
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path (%s)' % e)
     comm, host_sync, comm_error = None, None, None
-    if world > 1:
-        # A rank that never reaches the communicator's set-up would leave the others in ncclCommInitRank for
-        # good: a watchdog ends this rank instead (the launcher then ends the job) -- cancelled once the ranks
-        # have met in their first barrier.
-        import signal
+    # A rank whose peers are gone would wait in an RCCL collective for ever (and one that never reaches the
+    # communicator's set-up leaves the others in ncclCommInitRank): a watchdog, re-armed around the set-up, every
+    # barrier and every timed region, ends this rank instead -- the launcher / _supervise then ends the job.
+    import signal
+    watch = {'what': ''}
 
-        def _stuck(signum, frame):
-            sys.stderr.write('[bench] rank %d: the ranks did not meet within 600 s (RCCL set-up or the first '
-                             'barrier); giving up\n' % rank)
-            sys.stderr.flush()
-            os._exit(3)
+    def _stuck(signum, frame):
+        sys.stderr.write('[bench] rank %d: no progress in %s within its limit; giving up\n' % (rank, watch['what']))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def arm(seconds, what):
+        if world > 1:
+            watch['what'] = what
+            signal.alarm(int(seconds))
+
+    def disarm():
+        if world > 1:
+            signal.alarm(0)
+    if world > 1:
         signal.signal(signal.SIGALRM, _stuck)
-        signal.alarm(600)
+        arm(600, 'RCCL set-up and the first barrier')
     if world > 1 or args.comm:
         try:
             # librccl prints a version banner on stdout when it starts: the job's stdout is ONE JSON line, so the
@@ -255,26 +361,49 @@ def main():
                 sys.stdout.flush()
                 os.dup2(saved_out, 1)
                 os.close(saved_out)
-        except Exception as e:      # RCCL missing or the ranks could not meet
+        except Exception as e:      # RCCL missing, the ranks could not meet, or the first collective failed
+            if comm is not None:    # made, but its first barrier failed: not usable
+                try:
+                    comm.close()
+                except Exception:
+                    pass
+                comm = None
+            comm_error = '%s: %s' % (type(e).__name__, e)
             if world == 1:
                 raise
-            # Degraded mode, said loudly in config.exchange: the ranks still keep the timing protocol
+            if not args.allow_no_exchange:
+                # a whole-node number without the exchange step in it is not the metric: leave with an error
+                # (every rank fails the same way; the launcher / _supervise ends the job)
+                sys.stderr.write('[bench] rank %d: RCCL exchange unavailable (%s); no result (--allow-no-exchange '
+                                 'times the ranks without it)\n' % (rank, comm_error))
+                if rank == 0:
+                    print(json.dumps({'metric': 'frame-pairs/sec (whole node) KITTI-shape tau=2', 'value': None,
+                                      'unit': 'frame-pairs/s', 'n_gpus': n_gpus,
+                                      'error': 'no detection records exchanged: ' + comm_error}))
+                    sys.stdout.flush()
+                os._exit(4)
+            # Degraded mode, asked for and said loudly in config.exchange: the ranks keep the timing protocol
             # (barriers and max over ranks through files), but NO records are exchanged
-            comm_error = '%s: %s' % (type(e).__name__, e)
             sys.stderr.write('[bench] rank %d: RCCL exchange unavailable (%s); host barrier only\n'
                              % (rank, comm_error))
             host_sync = sharding.HostBarrier(rank, world)
+        disarm()
+    if comm is not None and args.late_peer_ms > 0:
+        comm.set_late_peer(args.late_peer_ms * 1e3)
     computed = args.heads == 'computed'
+    comm_stream = os.environ.get('DODT_BENCH_COMM_STREAM', 'own' if world > 1 else 'side')
     made = []   # pipelines built so far: later ones reuse the first one's streams
 
     def measure(conv_dtype, steps, warmup, head_dtype='f32', cfg=cfg, proposals=args.proposals,
-                from_host=False, pps=args.pairs_per_step, detail=False):
+                from_host=False, pps=args.pairs_per_step, detail=False, hbm_detail=False, points=args.points,
+                tau=args.tau, n_boxes=args.boxes, computed=computed, keep_records=0):
         """`steps` timed steps of the pipeline built for conv_dtype; with detail, then the conv
-        stacks alone layer by layer (roofline) and the HBM-bound kernels alone."""
+        stacks alone layer by layer (roofline); with hbm_detail the HBM-bound kernels alone.
+        keep_records: download the records of that many of the last steps (for the host's temporal module)."""
         fps = cfg['frames_per_sample']
         feat_c = 256 if cfg['extractor'] == 'vgg' else 32
         pipe = FramePairPipeline(ctx, cfg, **synth.pipeline_weights(cfg),
-                                 n_points_max=args.points, rpn_nms_size=proposals,
+                                 n_points_max=points, rpn_nms_size=proposals,
                                  pairs_per_step=pps,
                                  head_params=synth.head_params(feat=feat_c) if computed else None,
                                  conv_dtype=conv_dtype, head_dtype=head_dtype,
@@ -304,8 +433,8 @@ def main():
             pts, imgs, heads = [], [], []
             for j in range(pps):
                 seq = (rank * n_batches + i) * pps + j
-                for f in ((2 * i, 2 * i + 2) if fps == 2 else (2 * i,)):      # tau = 2
-                    pts.append(synth.lidar_frame(seq, f, args.points))
+                for f in ((tau * i, tau * i + tau) if fps == 2 else (tau * i,)):
+                    pts.append(synth.lidar_frame(seq, f, points, n_boxes))
                     imgs.append(ctx.array(synth.image_frame(seq, f)))
                     if not computed:
                         heads.append({k: ctx.array(v) for k, v in
@@ -315,7 +444,7 @@ def main():
             if from_host:   # the same frames in page-locked host memory (PCIe-inclusive run)
                 b['h_pts'], b['h_imgs'] = [], []
                 for p_, d_img in zip(pts, imgs):
-                    hp = ctx.pinned((args.points, 4), np.float32)
+                    hp = ctx.pinned((points, 4), np.float32)
                     hp.a[:len(p_)] = p_
                     hi = ctx.pinned(d_img.shape, np.uint8)
                     hi.a[...] = d_img.download()
@@ -324,8 +453,11 @@ def main():
             batches.append(b)
 
         state = {'sent': 0, 'last_block': None}     # steps whose records have been shipped
-        if comm is not None and os.environ.get('DODT_BENCH_COMM_STREAM', 'side') == 'side':
-            # the exchange on frame 1's side stream instead of a fifth stream (DODT_BENCH_COMM_STREAM=own)
+        # Which stream carries the collectives (measured with a late peer injected): with
+        # peers (world > 1) the communicator's OWN stream -- a rank that arrives late at a gather then holds that
+        # stream only, not a frame's prep and tail; with one rank (--comm) frame 1's side stream, which saves the
+        # fifth stream.  DODT_BENCH_COMM_STREAM=own|side overrides.
+        if comm is not None and comm_stream == 'side':
             comm.attach(pipe.sides[-1])
 
         def gather_block(b):
@@ -356,20 +488,22 @@ def main():
                 gather_block((state['sent'] // G) % 2)
 
         def barrier():
+            arm(300, 'a barrier')
             ctx.sync()                  # finish() joined every stream of the pipeline into this one
             if comm is not None:
                 comm.barrier()          # drains the side stream, then all ranks meet
             elif host_sync is not None:
                 host_sync.barrier()
-            if world > 1:
-                signal.alarm(0)         # the ranks have met: the set-up watchdog retires
+            disarm()
 
         # steps are pipelined two deep inside pipe.run(); finish() drains the last one, so
         # exactly `steps` complete steps (convs AND tails) lie inside the timed region
+        arm(300 + 0.1 * (warmup + steps), 'the warm-up steps')
         for i in range(warmup):
             step(i)
         drain()
         barrier()
+        arm(300 + 0.1 * steps, 'the timed steps')
         # one HIP event per step on the main stream: event i fires when step i's convs and step
         # i-1's tail are done, so the deltas show a slow fill / drain step or a clock ramp that
         # the single wall-clock window hides
@@ -389,19 +523,32 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         step_ms = [ctx.elapsed_ms(i, ctx, i + 1) for i in range(n_ev + 1)]
+        arm(300, 'the max over ranks')
         if comm is not None:
             elapsed = comm.max_over_ranks(elapsed)
         elif host_sync is not None:
             elapsed = host_sync.max_over_ranks(elapsed)
+        disarm()
         res = dict(elapsed=elapsed, host_enqueue_ms=host_enqueue_ms, step_ms=step_ms, host_ms=host_ms,
                    flops=pipe.flops_per_step(), mfma_flops=pipe.mfma_flops_per_step(),
                    head_gflop=pipe.head_flops_per_step() / 1e9, conv_bytes=pipe.conv_bytes_per_step(),
                    anchors=list(pipe.last_anchor_counts), steps=steps, pps=pps)
+        if keep_records:
+            # what the temporal module gets: the last steps' records in step order (slot k % 2G of the ring)
+            ring, cring = rec_ring.download(), cnt_ring.download()
+            res['records'] = []
+            for k_ in range(max(0, pipe.step_idx - min(keep_records, 2 * G)), pipe.step_idx):
+                for j in range(pps):
+                    c_ = cring[k_ % (2 * G), j]
+                    res['records'].append(np.concatenate([ring[k_ % (2 * G), j, f, :c_[f]] for f in range(fps)]))
         if comm is not None and rank == 0 and state['last_block'] is not None:
             # the exchange really happened: rank 0's own part of the last message equals its records
             b = state['last_block']
             g = gathered[b].download()[rank * G * pps:(rank + 1) * G * pps]
             res['gather_ok'] = bool(np.array_equal(g, blocks[b][0].download()) and np.abs(g).max() > 0)
+            if not res['gather_ok']:
+                raise RuntimeError("the all-gather's output does not hold rank 0's own records: the exchange step "
+                                   'did not do its work')
 
         # ---- the conv stacks alone (each net by itself on its own stream, so that kernel
         #      durations do not overlap), layer by layer: HIP events on the stream the kernels run on
@@ -441,47 +588,59 @@ def main():
                 pipe.img_net.forward_device(None, pipe.feat[0]['img_feat'], pipe.feat[0]['img_bneck'])
                 ctx.wait_for(pipe.img_ctx)
             res['both_ms'] = ctx.timer_stop() / reps
-            # ---- the HBM-bound kernels alone, on the inputs the last step left behind -----------
-            if fps == 2 and computed and cfg['extractor'] != 'vgg':
-                hreps = 20
-                fr, feat = pipe.fr, pipe.feat[(pipe.step_idx - 1) & 1]
-                n_pts = batches[0]['n'][0]
+        # ---- the HBM-bound kernels alone, on the inputs the last step left behind -----------
+        if hbm_detail and fps == 2 and computed and cfg['extractor'] != 'vgg':
+            hreps = 20
+            fr, feat = pipe.fr, pipe.feat[(pipe.step_idx - 1) & 1]
+            n_pts = batches[0]['n'][0]
 
-                def timed(fn):
+            def timed(fn):
+                fn()
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(hreps):
                     fn()
-                    ctx.sync()
-                    ctx.timer_start()
-                    for _ in range(hreps):
-                        fn()
-                    return ctx.timer_stop() / hreps * 1e3      # us
-                bev_hw, FC = (pipe.bev_fh, pipe.bev_fw), pipe.feat_c
-                feat_b0 = feat['bev_feat'].offset(0, bev_hw + (FC,))
-                feat_b1 = feat['bev_feat'].offset(4 * pipe.bev_fh * pipe.bev_fw * FC, bev_hw + (FC,))
-                d_bev = ctx.empty((pipe.bev_h, pipe.bev_w, cfg['bev_depth']), np.float32)
-                n_top = int(fr[0]['top_count'].download()[0])
-                out_b = n_top * ROI * ROI * FC * 4
-                hbm = []
-                us = timed(lambda: ops.bev_slices(ctx, batches[0]['pts'][0], n_pts, pipe.bp, d_bev, fr[0]['occ']))
-                hbm.append(dict(kernel='hipMemsetAsync + vox_scatter + vox_finalize',
-                                stage='a0-a3 voxeliser, %d points -> (700,800,6) maps' % n_pts,
-                                algorithmic_bytes=16 * n_pts + pipe.bev_h * pipe.bev_w * cfg['bev_depth'] * 4,
-                                us=us))
-                us = timed(lambda: ops.crop_and_resize(ctx, feat_b0, bev_hw + (FC,), fr[0]['top_bev'], pipe.P,
-                                                       fr[0]['top_count'], (ROI, ROI), fr[0]['bev_rois']))
-                hbm.append(dict(kernel='crop_kernel<4>', stage='a11 stage-2 ROI crop, %d proposals x 7x7x%d, BEV map'
-                                % (n_top, FC),
-                                algorithmic_bytes=16 * n_top + min(4 * out_b, pipe.bev_fh * pipe.bev_fw * FC * 4) + out_b,
-                                us=us))
-                corr_map = pipe.head_scratch[0]['corr_map']
-                us = timed(lambda: ops.correlation(ctx, feat_b0, feat_b1, bev_hw + (FC,), CORR_MAX_DISP,
-                                                   CORR_STRIDE2, CORR_PAD, corr_map))
-                hbm.append(dict(kernel='correlation_kernel', stage='f1 correlation of the pair\'s BEV features',
-                                algorithmic_bytes=(2 * FC + CORR_CH) * pipe.bev_fh * pipe.bev_fw * 4, us=us))
-                for h in hbm:
-                    h['us'] = round(h['us'], 2)
-                    h['gbps'] = round(h['algorithmic_bytes'] / h['us'] / 1e3, 1)
-                    h['frac_of_hbm_peak'] = round(h['gbps'] / HBM_PEAK, 4)
-                res['hbm'] = hbm
+                return ctx.timer_stop() / hreps * 1e3      # us
+            bev_hw, FC = (pipe.bev_fh, pipe.bev_fw), pipe.feat_c
+            feat_b0 = feat['bev_feat'].offset(0, bev_hw + (FC,))
+            feat_b1 = feat['bev_feat'].offset(4 * pipe.bev_fh * pipe.bev_fw * FC, bev_hw + (FC,))
+            d_bev = ctx.empty((pipe.bev_h, pipe.bev_w, cfg['bev_depth']), np.float32)
+            n_top = int(fr[0]['top_count'].download()[0])
+            out_b = n_top * ROI * ROI * FC * 4
+            hbm = []
+            us = timed(lambda: ops.bev_slices(ctx, batches[0]['pts'][0], n_pts, pipe.bp, d_bev, fr[0]['occ']))
+            hbm.append(dict(kernel='hipMemsetAsync + vox_scatter + vox_finalize',
+                            stage='a0-a3 voxeliser, %d points -> (700,800,6) maps' % n_pts,
+                            algorithmic_bytes=16 * n_pts + pipe.bev_h * pipe.bev_w * cfg['bev_depth'] * 4,
+                            us=us))
+            us = timed(lambda: ops.crop_and_resize(ctx, feat_b0, bev_hw + (FC,), fr[0]['top_bev'], pipe.P,
+                                                   fr[0]['top_count'], (ROI, ROI), fr[0]['bev_rois']))
+            hbm.append(dict(kernel='crop_kernel<4>', stage='a11 stage-2 ROI crop, %d proposals x 7x7x%d, BEV map'
+                            % (n_top, FC),
+                            algorithmic_bytes=16 * n_top + min(4 * out_b, pipe.bev_fh * pipe.bev_fw * FC * 4) + out_b,
+                            us=us))
+            corr_map = pipe.head_scratch[0]['corr_map']
+            us = timed(lambda: ops.correlation(ctx, feat_b0, feat_b1, bev_hw + (FC,), CORR_MAX_DISP,
+                                               CORR_STRIDE2, CORR_PAD, corr_map))
+            hbm.append(dict(kernel='correlation_kernel', stage='f1 correlation of the pair\'s BEV features',
+                            algorithmic_bytes=(2 * FC + CORR_CH) * pipe.bev_fh * pipe.bev_fw * 4, us=us))
+            # NMS #1 alone on the last step's candidates (n(n-1)/2 pair tests, bytes =
+            # 20 n + 8 n ceil(n/64); latency-bound, the bandwidth fraction is informative only)
+            n_c = int(pipe.last_anchor_counts[0])
+            d_sel, d_cnt = ctx.empty((pipe.P,), np.int32), ctx.zeros((1,), np.int32)
+            us = timed(lambda: ops.nms(ctx, fr[0]['prop_bev'], fr[0]['scores'], n_c, None, pipe.P,
+                                       cfg['rpn_nms_iou_thresh'], d_sel, d_cnt))
+            hbm.append(dict(kernel='nms_*', stage='a13 NMS #1, %d candidates -> %d at IoU %.2f'
+                            % (n_c, int(d_cnt.download()[0]), cfg['rpn_nms_iou_thresh']),
+                            algorithmic_bytes=20 * n_c + 8 * n_c * ((n_c + 63) // 64), us=us,
+                            pair_tests=n_c * (n_c - 1) // 2))
+            for h in hbm:
+                h['us'] = round(h['us'], 2)
+                h['gbps'] = round(h['algorithmic_bytes'] / h['us'] / 1e3, 1)
+                h['frac_of_hbm_peak'] = round(h['gbps'] / HBM_PEAK, 4)
+                if 'pair_tests' in h:
+                    h['pair_tests_per_s'] = float('%.4g' % (h['pair_tests'] / (h['us'] * 1e-6)))
+            res['hbm'] = hbm
         pipe.close()
         return res
 
@@ -493,7 +652,8 @@ def main():
         gc.collect()
         gc.freeze()
     pps = args.pairs_per_step
-    m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype, detail=True)
+    m = measure(args.conv_dtype, args.steps, args.warmup, args.head_dtype, detail=True, hbm_detail=True,
+                keep_records=16)
     elapsed, host_enqueue_ms, conv_ms, reps = m['elapsed'], m['host_enqueue_ms'], m['conv_ms'], m['reps']
     alt = None
     if not args.no_alt and world == 1:      # (N > 1 runs measure the sharded path only)
@@ -535,6 +695,52 @@ def main():
                            'pinned host memory inside each step'
                            % (args.points, 2 * (args.points * 16 + 1242 * 375 * 3) / 1e6))
             alt['pcie_inclusive'] = r
+            if computed:
+                # BASELINE.json configs[4]: tau = 3, ~300k points per frame, 4096 proposals, heads computed
+                # (S + T), with its own HBM-side kernels alone
+                a = measure(args.conv_dtype, k, 2, args.head_dtype, points=300000, proposals=4096, tau=3,
+                            n_boxes=40, hbm_detail=True)
+                dj = _profile_json('dense_hbm_traffic.json')
+                for h in a.get('hbm', []):
+                    t = dj['kernels'].get(h['kernel']) if dj else None
+                    h['traffic'] = round(t['fetch_bytes'] + t['write_bytes']) if t else None
+                alt['dense_scene'] = {
+                    'config': 'BASELINE.json configs[4] on one GPU: tau = 3, 2 x 300k points (40 boxes), 4096 proposals, '
+                              'S+T path, %s convs / %s heads' % (args.conv_dtype, args.head_dtype),
+                    'value': round(k / a['elapsed'], 3), 'unit': 'frame-pairs/s', 'steps': k,
+                    'ms_per_step': round(a['elapsed'] / k * 1e3, 4), 'anchors_kept': a['anchors'],
+                    'head_gflop_per_step': round(a['head_gflop'], 2), 'hbm': a.get('hbm'),
+                    'traffic_head': dj.get('head') if dj else None,
+                    'traffic_source': dj.get('source') if dj else None}
+            # BASELINE.json configs[1]: tau = 1 Siamese (S) path, heads' outputs injected from HBM
+            a = measure(args.conv_dtype, k, 2, 'f32', tau=1, computed=False)
+            alt['s_path'] = {'config': 'BASELINE.json configs[1]: DODT tau = 1 Siamese (S), batch = 1 frame pair, '
+                                       '%s; correlation branch and dense heads NOT run, their outputs injected' % args.conv_dtype,
+                             'value': round(k / a['elapsed'], 3), 'unit': 'frame-pairs/s', 'steps': k,
+                             'ms_per_step': round(a['elapsed'] / k * 1e3, 4)}
+            if args.sustained_steps > 0:
+                # the headline workload over seconds instead of a fraction of one: steady-state clocks and
+                # temperature, step-time percentiles from the host's per-step enqueue-to-enqueue times (the host
+                # runs one step ahead of the GPU, so over a long run they are the GPU's step times)
+                n_s = args.sustained_steps
+                a = measure(args.conv_dtype, n_s, args.warmup, args.head_dtype)
+                ev = np.asarray(a['step_ms'][:-1])
+                hs = np.asarray(a['host_ms'][len(a['host_ms']) // 10:])
+                alt['sustained'] = {
+                    'config': 'the headline workload, %d timed steps' % n_s,
+                    'value': round(n_s * a['pps'] / a['elapsed'], 3), 'unit': 'frame-pairs/s', 'steps': n_s,
+                    'seconds': round(a['elapsed'], 3), 'ms_per_step': round(a['elapsed'] / n_s * 1e3, 4),
+                    'step_ms_percentiles_host': {q: round(float(np.percentile(hs, p_)), 3) for q, p_ in
+                                                 (('p01', 1), ('p50', 50), ('p90', 90), ('p99', 99), ('max', 100))},
+                    'step_ms_first_%d_events' % len(ev): {'median': round(float(np.median(ev)), 3),
+                                                          'max': round(float(ev.max()), 3)},
+                    'ms_per_step_by_quarter': [round(float(np.mean(q_)), 4) for q_ in np.array_split(np.asarray(a['host_ms']), 4)]}
+            if computed and m.get('records'):
+                alt['temporal_host'] = temporal_host(m_pool, m_cores, m['records'], args.tau,
+                                                     world * args.steps * pps / elapsed)
+        if m_pool is not None:
+            m_pool.close()
+            m_pool.join()
 
     # ---- roofline of the dominant kernel ---------------------------------------------------------
     # Everything below is measured in this run with HIP events on the streams the kernels run on;
@@ -545,8 +751,8 @@ def main():
     n_launch = sum(k_['launches'] for k_ in by_kernel.values())
     layers_ms = sum(k_['ms'] for k_ in by_kernel.values())
     peak = FP32_MFMA_PEAK if args.conv_dtype == 'f32' else BF16_MFMA_PEAK
-    tj = _profile_json({'f32': 'r3_conv_traffic.json', 'f32s': 'r3f32s_conv_traffic.json',
-                        'bf16': 'r3bf16_conv_traffic.json'}[args.conv_dtype])
+    # (written by tools/summarize_profile.py with the head they were taken at: `traffic_head`)
+    tj = _profile_json('conv_traffic_%s.json' % args.conv_dtype)
     traffic = tj['kernels'].get(dom['kernel']) if tj else None
     kernels = []
     for k_ in sorted(by_kernel.values(), key=lambda k_: -k_['ms']):
@@ -570,6 +776,7 @@ def main():
         traffic=(round(traffic['fetch_bytes_per_launch'] + traffic['write_bytes_per_launch'])
                  if traffic else None),
         traffic_unit='bytes/launch', traffic_source=tj['source'] if tj else None,
+        traffic_head=tj.get('head') if tj else None,
         algorithmic_bytes_per_launch=round(by_kernel[d['kernel']]['bytes'] / d['launches_per_step']),
         arithmetic={'f32': 'fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2), peak 157.3 TFLOP/s dense',
                     'f32s': 'three bf16 MFMAs per product term (split mode), fp32 accumulate',
@@ -591,11 +798,12 @@ def main():
                 for i, l in enumerate(m['layers'])])
     hbm = m.get('hbm')
     if hbm:
-        hj = _profile_json('r3_hbm_traffic.json')
+        hj = _profile_json('hbm_traffic.json')
         for h in hbm:
             t = hj['kernels'].get(h['kernel']) if hj else None
             h['traffic'] = round(t['fetch_bytes'] + t['write_bytes']) if t else None
             h['traffic_source'] = hj['source'] if (hj and t) else None
+            h['traffic_head'] = hj.get('head') if (hj and t) else None
         roofline['hbm'] = hbm
 
     if rank == 0:
@@ -618,9 +826,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.conv_dtype, 'data': 'synthetic',
             'head_dtype': args.head_dtype,
-            'config': {'workload': ('DODT tau=2 frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
+            'config': {'workload': ('DODT tau=%d frame pair: 2 x %dk pts + 2 x 1242x375 RGB, '
                                     'pyramid_cars_with_aug_dt_5_tracking (box_4ca), %d proposals, '
-                                    '%s' % (args.points // 1000, args.proposals,
+                                    '%s' % (args.tau, args.points // 1000, args.proposals,
                                             'S+T path: correlation + dense heads on the device'
                                             if computed else 'S path (heads injected)'))
                        if args.config == 'dodt' else
@@ -629,9 +837,13 @@ def main():
                         % (args.points // 1000, args.proposals)),
                        'head_gflop_per_step': round(m['head_gflop'], 2),
                        'pairs_per_step_per_gpu': pps, 'parallelism': 'pair-shard x%d' % world,
-                       'exchange': ('RCCL all-gather of (%d steps x pairs,2,100,17) f32 + counts every %d steps, side '
-                                    'stream, C-ABI (no PyTorch)%s' % (max(1, args.gather_every), max(1, args.gather_every),
-                                                                     "; rank 0's part verified" if m.get('gather_ok') else '')
+                       'exchange': ('RCCL all-gather of (%d steps x pairs,2,100,17) f32 + counts every %d steps, on %s, '
+                                    'C-ABI (no PyTorch)%s%s' % (max(1, args.gather_every), max(1, args.gather_every),
+                                                               "the communicator's own stream" if comm_stream == 'own'
+                                                               else "frame 1's side stream",
+                                                               "; rank 0's part verified" if m.get('gather_ok') else '',
+                                                               '; a %.1f ms late peer injected in front of every gather'
+                                                               % args.late_peer_ms if args.late_peer_ms > 0 else '')
                                     ) if comm is not None else ('none (one rank)' if comm_error is None else
                                                                'FAILED, no records exchanged, host barrier only: ' + comm_error),
                        'conv_mode': os.environ.get('DODT_CONV_WINO', 'default'),

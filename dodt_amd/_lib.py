@@ -141,6 +141,7 @@ SIGNATURES = {
     'dodt_comm_destroy': (_i, [_vp]),
     'dodt_comm_attach': (_i, [_vp, _vp]),
     'dodt_comm_rank': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'dodt_comm_set_late_peer': (_i, [_vp, _d]),
     'dodt_all_gather_records': (_i, [_vp, _vp, _i, _pf, _pi32, _i, _i, _i, _i, _pf, _pi32]),
     'dodt_comm_join': (_i, [_vp, _i, _vp]),
     'dodt_comm_sync': (_i, [_vp]),

@@ -278,6 +278,43 @@ def _iou_3d_kitti_many(box3d, boxes3d):
     return three_d_iou_matrix(_kitti_rows(box3d), _kitti_rows(np.stack([np.asarray(b, np.float64) for b in boxes3d])))[0]
 
 
+def encode_tracking_dets(pairs, calib_p2, image_size, classes, threshold):
+    """encoder_tracking_dets + decode_tracking_file (dt_evaluator_utils.py:368-434) without the text
+    files in between.  pairs: [(frame_0, frame_1, records (n,17))] of one sequence in frame order, the
+    records as the device writes them.  A pair's keyframe-0 detections (with 'offsets' = the box shifted
+    by the correlation head into keyframe 1) go to dets_for_track, its keyframe-1 detections to
+    dets_for_ious, both as KITTI label rows (convert_pred_to_kitti_format; the offsets rows are converted
+    on their own, so a shifted box that leaves the image drops out of ITS list only and the zip pairs what
+    is left, as in the reference).  Pairs without any detection are skipped."""
+    from dodt_amd.core.dt_inference_utils import convert_pred_to_kitti_format
+
+    def kitti(rows):
+        return convert_pred_to_kitti_format(rows, calib_p2, image_size, classes, threshold) if len(rows) else []
+
+    def item(frame_id, row, offset=None):
+        d = {'frame_id': str(frame_id), 'info': row[:4],
+             'boxes2d': np.array(row[4:8], dtype=np.float32),
+             'boxes3d': np.array(row[8:-1], dtype=np.float32),
+             'scores': np.array(row[-1], dtype=np.float32)}
+        if offset is not None:
+            d['offsets'] = np.array(offset[8:-1], dtype=np.float32)
+        return d
+
+    dets_for_track, dets_for_ious = [], [{}]
+    for frame_0, frame_1, rec in pairs:
+        rec = np.asarray(rec, dtype=np.float32).reshape(-1, 17)
+        r0, r1 = rec[rec[:, -1] == 0], rec[rec[:, -1] == 1]
+        k0, k1 = kitti(r0[:, :9]), kitti(r1[:, :9])
+        shifted = r0[:, :9].copy()
+        shifted[:, :7] = r0[:, 9:-1]
+        koff = kitti(shifted)
+        if len(k0) == 0 and len(k1) == 0:
+            continue
+        dets_for_track.append([item(frame_0, f, o) for f, o in zip(k0, koff)])
+        dets_for_ious.append([item(frame_1, f) for f in k1])
+    return dets_for_track, dets_for_ious
+
+
 def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_threshold, t_min):
     """dt_evaluator_utils.py:436-511.  dets_for_track[k]: detections of pair k's first frame
     (dicts with 'boxes3d' (7,) [h,w,l,x,y,z,ry], 'offsets' = the box shifted into the pair's

@@ -83,6 +83,15 @@ int load_rccl() {
 
 constexpr int kSlots = 4;
 
+// One wave that idles until `ticks` of the 100 MHz wall clock have passed (dodt_comm_set_late_peer).  The loop
+// ends by the clock, and by an iteration cap should the clock ever stand still: an s_sleep of 64 x 64 cycles
+// is >= 1.7 us at the highest shader clock, so `ticks / 64 + 1024` iterations always outlast `ticks`.
+__global__ void __launch_bounds__(64) late_peer_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long cap = ticks / 64 + 1024;
+    for (unsigned long long i = 0; i < cap && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace
 
 struct dodt_comm {
@@ -94,6 +103,7 @@ struct dodt_comm {
     hipEvent_t done[kSlots] = {};          // gather of slot s has left the side stream
     bool used[kSlots] = {};
     double* d_scalar = nullptr;            // 2 doubles for the host-value reductions
+    double late_peer_us = 0.0;             // measurement aid: idle time in front of every gather
 };
 
 extern "C" {
@@ -170,6 +180,13 @@ int dodt_comm_rank(const dodt_comm* c, int* rank, int* world) {
     return DODT_OK;
 }
 
+int dodt_comm_set_late_peer(dodt_comm* c, double microseconds) {
+    DODT_REQUIRE(c, "dodt_comm_set_late_peer: comm is NULL");
+    DODT_REQUIRE(microseconds >= 0.0 && microseconds <= 1e5, "dodt_comm_set_late_peer: %g us not in 0..100000", microseconds);
+    c->late_peer_us = microseconds;
+    return DODT_OK;
+}
+
 int dodt_all_gather_records(dodt_comm* c, dodt_ctx* producer, int slot, const float* d_records,
                             const int32_t* d_counts, int pairs, int frames, int max_det, int cols,
                             float* d_all_records, int32_t* d_all_counts) {
@@ -181,6 +198,11 @@ int dodt_all_gather_records(dodt_comm* c, dodt_ctx* producer, int slot, const fl
     DODT_HIP_CHECK(hipEventRecord(c->produced, producer->stream));
     DODT_HIP_CHECK(hipStreamWaitEvent(c->stream, c->produced, 0));
     const size_t n_rec = (size_t)pairs * frames * max_det * cols, n_cnt = (size_t)pairs * frames;
+    if (c->late_peer_us > 0.0) {
+        hipLaunchKernelGGL(late_peer_kernel, dim3(1), dim3(64), 0, c->stream,
+                           (unsigned long long)(c->late_peer_us * 100.0));
+        DODT_LAUNCH_CHECK();
+    }
     DODT_NCCL_CHECK(g_rccl.GroupStart());
     ncclResult_t r1 = g_rccl.AllGather(d_records, d_all_records, n_rec, ncclFloat32, c->comm, c->stream);
     ncclResult_t r2 = g_rccl.AllGather(d_counts, d_all_counts, n_cnt, ncclInt32, c->comm, c->stream);

@@ -93,6 +93,11 @@ class Communicator(object):
         """Run the collectives on ctx's stream from now on (no stream of the communicator's own)."""
         self._lib.check(self.lib.dodt_comm_attach(self.handle, ctx.handle), 'dodt_comm_attach')
 
+    def set_late_peer(self, microseconds):
+        """Measurement aid: every gather is preceded on its stream by an idle kernel of this length (a peer that
+        reaches the rendezvous late); 0 switches it off."""
+        self._lib.check(self.lib.dodt_comm_set_late_peer(self.handle, float(microseconds)), 'dodt_comm_set_late_peer')
+
     def join(self, slot, consumer):
         """`consumer`'s later work waits for the gather last enqueued with `slot`."""
         self._lib.check(self.lib.dodt_comm_join(self.handle, int(slot), consumer.handle),

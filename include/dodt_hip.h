@@ -439,6 +439,10 @@ int dodt_comm_destroy(dodt_comm* comm);
  * caller's kernels.  ctx must outlive the communicator. */
 int dodt_comm_attach(dodt_comm* comm, dodt_ctx* ctx);
 int dodt_comm_rank(const dodt_comm* comm, int* rank, int* world);
+/* Measurement aid: from now on every dodt_all_gather_records is preceded, on the stream that
+ * carries the collectives, by a one-wave kernel that idles for `microseconds` -- what that stream sees when a peer
+ * reaches the rendezvous late.  0 switches it off.  At most 100 000 us. */
+int dodt_comm_set_late_peer(dodt_comm* comm, double microseconds);
 int dodt_all_gather_records(dodt_comm* comm, dodt_ctx* producer, int slot, const float* d_records,
                             const int32_t* d_counts, int pairs, int frames, int max_det, int cols,
                             float* d_all_records, int32_t* d_all_counts);
