@@ -16,8 +16,6 @@ track_through_ious (avod/core/dt_evaluator_utils.py:436-511) is the tracker over
 of keyframe pairs: greedy IoU association of each track's last box, shifted by its
 correlation offsets, with the next pair's detections.
 """
-import copy
-
 import numpy as np
 
 
@@ -286,18 +284,24 @@ def encode_tracking_dets(pairs, calib_p2, image_size, classes, threshold):
     dets_for_ious, both as KITTI label rows (convert_pred_to_kitti_format; the offsets rows are converted
     on their own, so a shifted box that leaves the image drops out of ITS list only and the zip pairs what
     is left, as in the reference).  Pairs without any detection are skipped."""
-    from dodt_amd.core.dt_inference_utils import convert_pred_to_kitti_format
+    from dodt_amd.core.dt_inference_utils import kitti_label_table
 
+    # The reference's rows are strings (np.column_stack with the class names) that it parses back with
+    # np.array(row[...], dtype=np.float32): numpy prints a float64 in its shortest round-trip form, so the
+    # parsed value is float32(the 3-decimal float64) -- taken here without the text in between.
     def kitti(rows):
-        return convert_pred_to_kitti_format(rows, calib_p2, image_size, classes, threshold) if len(rows) else []
+        if len(rows) == 0:
+            return []
+        types, k = kitti_label_table(rows, calib_p2, image_size, threshold)
+        return [] if k is None else list(zip(types, k))
 
     def item(frame_id, row, offset=None):
-        d = {'frame_id': str(frame_id), 'info': row[:4],
-             'boxes2d': np.array(row[4:8], dtype=np.float32),
-             'boxes3d': np.array(row[8:-1], dtype=np.float32),
-             'scores': np.array(row[-1], dtype=np.float32)}
+        t, k = row
+        d = {'frame_id': str(frame_id), 'info': [classes[t], '-1', '-1', '-10.0'],
+             'boxes2d': k[4:8].astype(np.float32), 'boxes3d': k[8:15].astype(np.float32),
+             'scores': np.float32(k[15])}
         if offset is not None:
-            d['offsets'] = np.array(offset[8:-1], dtype=np.float32)
+            d['offsets'] = offset[1][8:15].astype(np.float32)
         return d
 
     dets_for_track, dets_for_ious = [], [{}]
@@ -322,29 +326,53 @@ def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_thresh
     that same frame ([{}] for k = 0, dt_evaluator_utils.py:398).  Returns the finished tracks:
     dicts 'trajectory' (list of detections), 'max_score', 'start_frame'.  The inputs are not
     modified (the reference appends merged detections to them)."""
-    dets_for_track = copy.deepcopy(dets_for_track)
-    dets_for_ious = copy.deepcopy(dets_for_ious)
+    # (the reference appends to and deletes from the lists it is given and sets 'offsets' on merged
+    #  detections: lists and dicts are copied here, the arrays inside are never written)
+    dets_for_track = [[dict(d) for d in f] for f in dets_for_track]
+    dets_for_ious = [[dict(d) for d in f] if isinstance(f, list) else f for f in dets_for_ious]
+
+    def boxes_of(items):
+        return _kitti_rows(np.stack([np.asarray(x['boxes3d'], np.float64) for x in items]))
 
     def merge_dets(dets, dets_iou):
+        """The reference's merge_dets: a detection of dets_iou that overlaps nothing in `dets` is appended to it
+        (with 'offsets' = its own box) -- `dets` grows while the loop runs, so later ones are also tested against
+        the ones appended before them.  Both IoU tables of the frame in two batches; the loop only reads them."""
         merged = dets
-        for item1 in dets_iou:
-            # `dets` grows while this loop runs (merged IS dets, as in the reference): one batch per item
-            if not (_iou_3d_kitti_many(item1['boxes3d'], [item2['boxes3d'] for item2 in dets]) > 0).any():
+        if len(dets_iou) == 0:
+            return merged
+        b_iou = boxes_of(dets_iou)
+        hits = (three_d_iou_matrix(b_iou, boxes_of(dets)) > 0).any(1) if len(dets) else np.zeros(len(dets_iou), bool)
+        among = three_d_iou_matrix(b_iou, b_iou) > 0
+        appended = []
+        for i, item1 in enumerate(dets_iou):
+            if not hits[i] and not among[i, appended].any():
                 item1['offsets'] = item1['boxes3d']
                 merged.append(item1)
+                appended.append(i)
         return merged
 
     tracks_active, tracks_finished = [], []
     for frame_num, dets in enumerate(dets_for_track):
         update_tracks = []
         dets_iou = dets_for_ious[frame_num]
-        for track in tracks_active:
+        # The reference walks the active tracks and, per track, (a) merges the two lists if their lengths differ
+        # -- which can only happen at the first track: afterwards both lose the same entry per match --, (b) takes
+        # the IoU of the track's shifted last box with every remaining detection.  Same decisions here with the
+        # merge done once and all IoUs of the frame in one batch; `alive` maps the shrinking lists' positions to
+        # columns of that matrix.
+        if tracks_active and len(dets) > 0:
+            if len(dets_iou) != len(dets):
+                merged = merge_dets(dets, dets_iou)
+                dets = [dict(d) for d in merged]
+                dets_iou = [dict(d) for d in merged]
+            ious_all = three_d_iou_matrix(
+                _kitti_rows(np.stack([np.asarray(t['trajectory'][-1]['offsets'], np.float64) for t in tracks_active])),
+                boxes_of(dets_iou))
+        alive = list(range(len(dets)))
+        for n, track in enumerate(tracks_active):
             if len(dets) > 0:
-                if len(dets_iou) != len(dets):
-                    merged = merge_dets(dets, dets_iou)
-                    dets = copy.deepcopy(merged)
-                    dets_iou = copy.deepcopy(merged)
-                ious = _iou_3d_kitti_many(track['trajectory'][-1]['offsets'], [x['boxes3d'] for x in dets_iou])
+                ious = ious_all[n, alive]
                 best = int(np.argmax(ious))
                 if ious[best] > iou_threshold:
                     track['trajectory'].append(dets[best])
@@ -352,6 +380,7 @@ def track_through_ious(dets_for_track, dets_for_ious, high_threshold, iou_thresh
                     update_tracks.append(track)
                     del dets[best]
                     del dets_iou[best]
+                    del alive[best]
             if len(update_tracks) == 0 or track is not update_tracks[-1]:
                 if track['max_score'] >= high_threshold and len(track['trajectory']) >= t_min:
                     tracks_finished.append(track)

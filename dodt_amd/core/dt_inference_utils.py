@@ -47,27 +47,36 @@ def project_boxes_to_image_space(boxes_3d, calib_p2, truncate=False, image_size=
     return box, valid
 
 
-def convert_pred_to_kitti_format(all_predictions, stereo_calib_p2, image_size, classes,
-                                 score_threshold):
-    """(n,17) records -> the reference's text table: rows [type, -1, -1, -10, x1, y1, x2, y2,
-    h, w, l, x, y, z, ry, score] as strings (np.column_stack of a str column and floats, as
-    the reference builds it), or [] when nothing survives."""
+def kitti_label_table(all_predictions, stereo_calib_p2, image_size, score_threshold):
+    """The numbers of convert_pred_to_kitti_format: (class indices (k,), table (k,16) float64 rounded to 3
+    decimals, columns [0, 0, 0, -10, x1, y1, x2, y2, h, w, l, x, y, z, ry, score]) of the records that
+    pass the score threshold and project into the image; (None, None) when nothing survives."""
     p = np.asarray(all_predictions, dtype=np.float64)
     p = p[p[:, 7] >= score_threshold]
     if len(p) == 0:
-        return []
+        return None, None
     boxes, valid = project_boxes_to_image_space(p[:, 0:7], stereo_calib_p2, truncate=True,
                                                 image_size=image_size)
     p, boxes = p[valid], boxes[valid]
     if len(boxes) == 0:
-        return []
+        return None, None
     k = np.zeros([len(boxes), 16])
-    obj_types = [classes[i] for i in p[:, 8].astype(np.int32)]
     k[:, 3] = -10
     k[:, 4:8] = boxes
     k[:, 8], k[:, 9], k[:, 10] = p[:, 5], p[:, 4], p[:, 3]
     k[:, 11:14] = p[:, 0:3]
     k[:, 14:16] = p[:, 6:8]
-    k = np.round(k, 3)
+    return p[:, 8].astype(np.int32), np.round(k, 3)
+
+
+def convert_pred_to_kitti_format(all_predictions, stereo_calib_p2, image_size, classes,
+                                 score_threshold):
+    """(n,17) records -> the reference's text table: rows [type, -1, -1, -10, x1, y1, x2, y2,
+    h, w, l, x, y, z, ry, score] as strings (np.column_stack of a str column and floats, as
+    the reference builds it), or [] when nothing survives."""
+    types, k = kitti_label_table(all_predictions, stereo_calib_p2, image_size, score_threshold)
+    if k is None:
+        return []
+    obj_types = [classes[i] for i in types]
     empty = -1 * np.ones((len(k), 2), dtype=np.int32)
     return np.column_stack([obj_types, empty, k[:, 3:16]])

@@ -59,7 +59,7 @@ class FramePairPipeline(object):
                  r0_rect=_config.KITTI_R0_RECT, tr_velo_to_cam=_config.KITTI_TR_VELO_TO_CAM,
                  image_wh=_config.KITTI_IMAGE_WH, n_points_max=120000, rpn_nms_size=1024,
                  pairs_per_step=1, side_streams=None, head_params=None, conv_dtype='f32',
-                 head_dtype='f32', reuse_streams_of=None):
+                 head_dtype='f32', reuse_streams_of=None, tail_sets=None):
         self.ctx = ctx
         self.cfg = cfg
         self.p2 = np.asarray(p2, dtype=np.float64)
@@ -80,12 +80,27 @@ class FramePairPipeline(object):
         # streams: conv stacks of the two nets side by side, per-frame work on its own.
         # A second pipeline in the same process takes the first one's streams
         # (`reuse_streams_of`): new ones would share hardware queues with them (see below).
+        # `tail_sets` (1 or 2; DODT_PIPE_TAIL_SETS overrides): sets of side streams.  With one set a frame's
+        # stream carries prep k, tail k-1, prep k+1, tail k, ... in a row, so a step cannot be shorter than a
+        # tail's dependent launch chain plus a prep -- what bounds the step once the convs run on the bf16 MFMA
+        # (chain 1.2 ms against 0.9 ms of convs).  With two sets the steps alternate between them by parity (set p:
+        # prep k, tail k, prep k+2, tail k+2, ...): the tails of consecutive steps overlap, every buffer a step
+        # touches is still used in stream order by its own parity's streams.
+        if tail_sets is None:
+            tail_sets = 2 if conv_dtype == 'bf16' else 1
+        tail_sets = int(os.environ.get('DODT_PIPE_TAIL_SETS', tail_sets))
+        if tail_sets not in (1, 2):
+            raise ValueError('tail_sets must be 1 or 2')
         if reuse_streams_of is not None:
             self.img_ctx = reuse_streams_of.img_ctx
-            self.sides = reuse_streams_of.sides
-            self.preps = reuse_streams_of.preps
+            self.stream_sets = list(reuse_streams_of.stream_sets)
+            while len(self.stream_sets) < tail_sets:
+                self.stream_sets.append(self._make_side_streams(ctx, side_streams))
+            self.stream_sets = self.stream_sets[:tail_sets]
         else:
-            self._make_streams(ctx, side_streams)
+            self.img_ctx = device.Context(ctx.device_id)
+            self.stream_sets = [self._make_side_streams(ctx, side_streams) for _ in range(tail_sets)]
+        self.sides, self.preps = self.stream_sets[0]      # (the first set: what one-set callers see)
         # ---- constants of the configuration, resident on the device ----------------
         boxes = gen.tile_anchors_3d(cfg['area_extents'], cfg['anchor_sizes'],
                                     cfg['anchor_stride'], cfg['ground_plane'])
@@ -133,11 +148,13 @@ class FramePairPipeline(object):
             if self.fps == 2:
                 self.corr_head = EarlyFusionFcLayers(ctx, head_params['corr'],
                                                      outputs=('off_out',), dtype=head_dtype)
-            self.head_scratch = [dict(rpn=self.rpn_head.make_scratch(N),
-                                      fc=self.avod_head.make_scratch(P),
-                                      corr_map=ctx.empty((self.bev_fh, self.bev_fw, CORR_CH), f32)
-                                      if self.fps == 2 else None)
-                                 for _ in self.sides]
+            # one scratch set per side stream of every set (the tails of two sets overlap)
+            self.head_scratch_sets = [[dict(rpn=self.rpn_head.make_scratch(N),
+                                            fc=self.avod_head.make_scratch(P),
+                                            corr_map=ctx.empty((self.bev_fh, self.bev_fw, CORR_CH), f32)
+                                            if self.fps == 2 else None)
+                                       for _ in sides] for sides, _ in self.stream_sets]
+            self.head_scratch = self.head_scratch_sets[0]
 
         # ---- work buffers ----------------------------------------------------------------
         FC = self.feat_c
@@ -202,24 +219,29 @@ class FramePairPipeline(object):
                 c.mark(slot)
                 self.marks['%d:%s' % (step, name)] = (c, slot)
 
-    def _make_streams(self, ctx, side_streams):
-        self.img_ctx = device.Context(ctx.device_id)
+    def _make_side_streams(self, ctx, side_streams):
+        """One set of side streams: (tails, preps), one of each per frame of a pair (or `side_streams`)."""
         n_side = min(self.nf, 2) if side_streams is None else int(side_streams)
         hp = os.environ.get('DODT_PIPE_PRIO', '0') == '1'
-        self.sides = [device.Context(ctx.device_id, high_priority=hp)
-                      for _ in range(max(n_side, 1))]   # tails
+        sides = [device.Context(ctx.device_id, high_priority=hp)
+                 for _ in range(max(n_side, 1))]   # tails
         # ROCm maps a process's streams onto 4 hardware queues; a fifth stream shares a queue
         # with another one and runs behind its launches (measured: 6 streams 164, 5 streams
         # 180, 4 streams 191 pairs/s), so by default a frame's prep and tail share a stream
         mode = os.environ.get('DODT_PIPE_STREAMS', 'shared')
         if mode == 'shared':      # frame f's prep and tail on one stream
-            self.preps = self.sides
+            preps = sides
         elif mode == 'one':       # all preps on one extra stream
             one = device.Context(ctx.device_id, high_priority=hp)
-            self.preps = [one for _ in self.sides]
+            preps = [one for _ in sides]
         else:
-            self.preps = [device.Context(ctx.device_id, high_priority=hp)
-                          for _ in range(max(n_side, 1))]
+            preps = [device.Context(ctx.device_id, high_priority=hp)
+                     for _ in range(max(n_side, 1))]
+        return sides, preps
+
+    def _streams(self, cur):
+        """(tail streams, prep streams) of the steps with parity `cur`."""
+        return self.stream_sets[cur % len(self.stream_sets)]
 
     def _views(self, arr, shape):
         n = int(np.prod(shape)) * 4
@@ -255,7 +277,8 @@ class FramePairPipeline(object):
         (the caller keeps the pinned buffers untouched until that step's prep has run, e.g.
         by alternating two sets)."""
         cur = self.step_idx & 1
-        ns = len(self.sides)
+        _, preps = self._streams(cur)
+        ns = len(preps)
         if not hasattr(self, 'stage'):
             H, W = self.image_wh[1], self.image_wh[0]
             self.stage = [[(self.ctx.empty((self.n_points_max, 4), np.float32),
@@ -263,7 +286,7 @@ class FramePairPipeline(object):
                           for _ in range(2)]
         d_pts, d_imgs = [], []
         for f in range(self.nf):
-            c = self.preps[f % ns]
+            c = preps[f % ns]
             dp, di = self.stage[cur][f]
             if n_points[f] > self.n_points_max:
                 raise ValueError('frame %d has more than n_points_max points' % f)
@@ -292,8 +315,9 @@ class FramePairPipeline(object):
         if (heads is None) != (self.rpn_head is not None):
             raise ValueError('pass `heads` exactly when the pipeline has no head_params')
         mean = (self.img_net._R_MEAN, self.img_net._G_MEAN, self.img_net._B_MEAN)
-        ns = len(self.sides)
         cur = self.step_idx & 1
+        sides, preps = self._streams(cur)
+        ns = len(sides)
         fr, feat = self.fr2[cur], self.feat[cur]
         bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w, self.cfg['bev_depth']))
         img_in = self._views(self.in_img[cur], (self.img_h, self.img_w, 4))
@@ -302,7 +326,7 @@ class FramePairPipeline(object):
         #    streams were told to wait for it when it was enqueued (below).
         k = self.step_idx
         for f in range(nf):
-            c, b = self.preps[f % ns], fr[f]
+            c, b = preps[f % ns], fr[f]
             self._mark(c, k, 'prep%d_start' % f)
             bp = self.bp
             if ego_motion is not None and self.fps == 2 and f % 2 == 1 \
@@ -318,7 +342,7 @@ class FramePairPipeline(object):
             ops.img_preprocess(c, d_images[f], (self.image_wh[1], self.image_wh[0]),
                                (self.img_h, self.img_w), 4, mean, img_in[f])
             self._mark(c, k, 'prep%d_end' % f)
-        for c in self.preps:
+        for c in preps:
             main.wait_for(c)
             self.img_ctx.wait_for(c)
         # -- a8-a10: conv stacks, all frames per launch, the two nets side by side --------
@@ -332,9 +356,10 @@ class FramePairPipeline(object):
         if self.pending is not None:
             self._wait_convs(self.pending)
             self._tail(self.pending)
-            for i, s in enumerate(self.sides):
+            p_sides, p_preps = self._streams(self.pending['cur'])
+            for i, s in enumerate(p_sides):
                 main.wait_for(s)       # previous step's records are complete on `main`
-                self.preps[i].wait_for(s)   # the NEXT step's prep reuses that tail's buffers
+                p_preps[i].wait_for(s)   # the next step of that parity reuses that tail's buffers: its prep waits
         self.pending = dict(cur=cur, heads=heads, step=k, rslot=k % len(self.rec2))
         # The tail of THIS step (next call) starts when these convs are done.  The point is marked now and waited
         # for when the tail is enqueued -- behind the NEXT step's prep on the same side stream, which therefore
@@ -344,7 +369,7 @@ class FramePairPipeline(object):
             main.mark(self.CONV_DONE_MARK + cur)
             self.img_ctx.mark(self.CONV_DONE_MARK + cur)
         else:
-            for s in self.sides:
+            for s in sides:
                 s.wait_for(main)
                 s.wait_for(self.img_ctx)
         self.step_idx += 1
@@ -356,8 +381,9 @@ class FramePairPipeline(object):
             self._wait_convs(self.pending)
             self._tail(self.pending)
             self.pending = None
-        for s in self.sides:
-            self.ctx.wait_for(s)
+        for sides, preps in self.stream_sets:
+            for s in set(sides) | set(preps):
+                self.ctx.wait_for(s)
         self.ctx.wait_for(self.img_ctx)
 
     CONV_DONE_MARK = 250        # mark slots 250, 251 of the conv contexts: end of a step's stacks, by parity
@@ -365,19 +391,21 @@ class FramePairPipeline(object):
     def _wait_convs(self, st):
         """The side streams wait for the conv stacks of step `st` (marked at the end of its run())."""
         if self.early_prep:
-            for s in self.sides:
+            for s in self._streams(st['cur'])[0]:
                 s.wait_mark(self.ctx, self.CONV_DONE_MARK + st['cur'])
                 s.wait_mark(self.img_ctx, self.CONV_DONE_MARK + st['cur'])
 
     def _tail(self, st):
         """Stages after the extractors for every frame of step `st` (a11-a14)."""
         cfg, nf = self.cfg, self.nf
-        ns = len(self.sides)
         cur = st['cur']
+        sides, preps = self._streams(cur)
+        ns = len(sides)
+        head_scratch = self.head_scratch_sets[cur % len(self.stream_sets)] if self.rpn_head is not None else None
         fr, feat = self.fr2[cur], self.feat[cur]
         heads = st['heads']
         # kept-anchor counts of that step: fetched by its prep streams, long complete
-        counts = [ops.fetch_i32_end(self.preps[f % ns], 2 * f + cur, 1)[0]
+        counts = [ops.fetch_i32_end(preps[f % ns], 2 * f + cur, 1)[0]
                   for f in range(nf)]
         self.last_anchor_counts = counts
         self.fr = fr
@@ -392,7 +420,7 @@ class FramePairPipeline(object):
         if os.environ.get('DODT_PIPE_NO_TAIL'):      # (tools/: the step without its tail)
             return
         if self.on_records_reuse is not None:
-            self.on_records_reuse(st['rslot'], self.sides)
+            self.on_records_reuse(st['rslot'], sides)
         computed = heads is None
         # The T branch of a pair hangs on frame 0's tail, which makes it half as long again as frame 1's.  Its map
         # and crops (not the head) therefore go onto frame 1's stream, between that frame's own crops and head:
@@ -414,9 +442,9 @@ class FramePairPipeline(object):
                                 out_box_stride=self.corr_head.in_ld)
 
         def frame(f):
-            c, b, A = self.sides[f % ns], fr[f], counts[f]
+            c, b, A = sides[f % ns], fr[f], counts[f]
             h = b if computed else heads[f]
-            scratch = self.head_scratch[f % ns] if computed else None
+            scratch = head_scratch[f % ns] if computed else None
             self._mark(c, st['step'], 'tail%d_start' % f)
             bneck_b = feat['bev_bneck'].offset(4 * bev_px * f, bev_hw + (1,))
             bneck_i = feat['img_bneck'].offset(4 * img_px * f, img_hw + (1,))
@@ -465,7 +493,7 @@ class FramePairPipeline(object):
                     # T branch: correlate the pair's BEV features, crop with frame 0's
                     # proposals (dt_rpn_model.py:324-331, dt_avod_model.py:267-273,300-304)
                     if split_t:
-                        c.wait_mark(self.sides[(f + 1) % ns], self.CORR_ROIS_MARK)
+                        c.wait_mark(sides[(f + 1) % ns], self.CORR_ROIS_MARK)
                     else:
                         t_branch_crops(c, f, scratch)
                     self._mark(c, st['step'], 'tail%d_corrmap' % f)
@@ -504,7 +532,7 @@ class FramePairPipeline(object):
                 drain(frame(f))
             return
         for f0 in range(0, nf, 2):
-            c0, c1 = self.sides[f0 % ns], self.sides[(f0 + 1) % ns]
+            c0, c1 = sides[f0 % ns], sides[(f0 + 1) % ns]
             g0, g1 = frame(f0), frame(f0 + 1)
             while next(g0) != 'crops':          # frame 0 up to its 7x7 crops: its proposals stand
                 pass
@@ -514,7 +542,7 @@ class FramePairPipeline(object):
             while next(g1) != 'crops':          # frame 1 up to its crops, then the T branch's map and crops
                 pass
             c1.wait_mark(c0, self.PROPOSALS_MARK)
-            t_branch_crops(c1, f0, self.head_scratch[(f0 + 1) % ns])
+            t_branch_crops(c1, f0, head_scratch[(f0 + 1) % ns])
             c1.mark(self.CORR_ROIS_MARK)
             drain(g1)
             drain(g0)                           # waits for CORR_ROIS_MARK: correlation head, NMS #2, records

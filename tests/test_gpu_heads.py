@@ -307,6 +307,8 @@ def _stagewise(ctx, conv_dtype, head_dtype, seq, frames, n_points, proposals):
 
 
 FREE_RUNNING_MODES = (('direct', '0'), ('F(2x2,3x3)', '2'), ('F(4x4,3x3)', '4'))
+# seeded pairs the free-running fractions are pooled over (sequence, frames): 8 frames, ~800 detections
+FREE_RUNNING_PAIRS = ((4, (0, 2)), (5, (1, 3)), (6, (0, 2)), (7, (2, 4)))
 _CHILD = '''
 import sys
 import numpy as np
@@ -316,29 +318,31 @@ from dodt_amd.pipeline import MAX_DET, FramePairPipeline
 C = config.PYRAMID_DODT
 ctx = device.default_context()
 pipe = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), rpn_nms_size=1024, head_params=synth.head_params())
-pts = [synth.lidar_frame(4, f) for f in (0, 2)]
-imgs = [synth.image_frame(4, f) for f in (0, 2)]
-pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts], [ctx.array(i) for i in imgs])
-pipe.finish()
-ctx.sync()
-recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
 out = dict(mode=np.int32(ctx.lib.dodt_conv_mode()))
-for f in range(2):
-    b = pipe.fr[f]
-    n_top = int(b['top_count'].download()[0])
-    n_det = int(b['det_count'].download()[0])
-    out['top%%d' %% f] = b['top_anchors'].download()[:n_top]
-    out['rec%%d' %% f] = recs[f][:n_det]
-    out['bev_rois%%d' %% f] = b['bev_rois'].download()[:n_top]
-    out['top_bev%%d' %% f] = b['top_bev'].download()[:n_top]
-    out['feat%%d' %% f] = pipe.feat[0]['bev_feat'].download()[f]
+for k, (seq, frames) in enumerate(%r):
+    pts = [synth.lidar_frame(seq, f) for f in frames]
+    imgs = [synth.image_frame(seq, f) for f in frames]
+    cur = pipe.run([ctx.array(p) for p in pts], [len(p) for p in pts], [ctx.array(i) for i in imgs])
+    pipe.finish()
+    ctx.sync()
+    recs = pipe.d_records.download().reshape(-1, MAX_DET, 17)
+    for f in range(2):
+        b = pipe.fr[f]
+        n_top = int(b['top_count'].download()[0])
+        n_det = int(b['det_count'].download()[0])
+        out['p%%d_top%%d' %% (k, f)] = b['top_anchors'].download()[:n_top]
+        out['p%%d_rec%%d' %% (k, f)] = recs[f][:n_det]
+        if k == 0:
+            out['bev_rois%%d' %% f] = b['bev_rois'].download()[:n_top]
+            out['top_bev%%d' %% f] = b['top_bev'].download()[:n_top]
+            out['feat%%d' %% f] = pipe.feat[cur]['bev_feat'].download()[f]
 np.savez(sys.argv[1], **out)
 pipe.close()
 '''
 
 
 def _matched(got, ref, tol):
-    """Fraction of ref rows with an unused got row within tol (1 + 0.1 |ref|) per element
+    """Number of ref rows with an unused got row within tol (1 + 0.1 |ref|) per element
     (positions reach 70 m), greedy in ref order; also the list of unmatched ref rows."""
     used = np.zeros(len(got), bool)
     hits, missed = 0, []
@@ -351,29 +355,30 @@ def _matched(got, ref, tol):
             hits += 1
         else:
             missed.append(i)
-    return hits / max(len(ref), 1), missed
+    return hits, missed
 
 
 def test_pair_free_running_by_conv_mode(tmp_path):
-    """Free-running check: the whole pair on the device -- extractors, heads, both
+    """Free-running check (VERDICT r2 #1, r3 #1c): whole pairs on the device -- extractors, heads, both
     NMS, records --, nothing fed back, once per form of the fp32 3x3 stride-1 layers (direct,
     Winograd F(2x2,3x3), Winograd F(4x4,3x3); child processes, the library reads DODT_CONV_WINO once),
     against the oracle run end to end on the same raw inputs in two arithmetics:
       f32    the oracle's own float32 order -- one legal evaluation, like the reference's TF-CPU
-             (Eigen) convolutions (bev_vgg_pyramid.py:57-169) are another;
+             (Eigen) convolutions (bev_vgg_pyramid.py:57-169) are another (first pair only: the floor);
       exact  float64 conv sums rounded once per layer (tfops.exact_sums): what every legal float32
              order scatters around.  `f32 vs exact` is printed as the floor: the drift of a correct
              float32 implementation that merely sums in another order.
     Not an index-exact statement (a logit that differs in its last bits may reorder near-tied NMS
     candidates; test_pair_with_computed_heads_matches_oracle_stagewise is the parity statement per
     stage): detections are matched greedily by box distance and the fractions that agree to 1e-4,
-    1e-3, 1e-2 and 5e-2 (x (1 + 0.1 |value|); 7 box parameters + score) are reported per mode, the
-    unmatched ones are named with the stage at which they diverge, and the table goes to
-    gpurun_out/free_running.json (DESIGN.md section 2 quotes it).
-    The rule that picks the default: the fastest form whose detection agreement at
+    1e-3, 1e-2 and 5e-2 (x (1 + 0.1 |value|); 7 box parameters + score) are POOLED over the eight frames
+    of four seeded pairs (~800 detections: the standard error of a fraction near 0.7 is 0.016; on one
+    pair it was 0.035, the size of the differences the rule decides on).  The table goes to
+    gpurun_out/free_running.json (DESIGN.md section 2a quotes it).
+    The rule that picks the default: the fastest form whose pooled detection agreement at
     1e-3 with the exact oracle is within 0.10 of the direct kernels'.  Asserted: the library's
     default obeys the rule; every form keeps >= 95 % of the proposals within 1e-3 and the detection
-    count within 10 %; every form's 5e-2 agreement is within 0.05 of the direct kernels'."""
+    count within 10 % on every frame; every form's pooled 5e-2 agreement is within 0.05 of the direct kernels'."""
     import json
     import os
     import subprocess
@@ -381,67 +386,73 @@ def test_pair_free_running_by_conv_mode(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hp = synth.head_params()
     w = synth.pipeline_weights(C)
-    frames = (0, 2)
-    pts = [synth.lidar_frame(4, f) for f in frames]
-    imgs = [synth.image_frame(4, f) for f in frames]
-    inps = [opipe.frame_inputs(p, C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2, synth.IMAGE_WH)
-            for p in pts]
-    oracle = {}
-    for name in ('f32', 'exact'):
-        if name == 'exact':
-            with tfops.exact_sums():
-                feats = [opipe.extract(inps[k]['bev'], imgs[k], w['bev_params'], w['img_params'],
-                                       C['img_dims']) for k in range(2)]
-        else:
-            feats = [opipe.extract(inps[k]['bev'], imgs[k], w['bev_params'], w['img_params'],
-                                   C['img_dims']) for k in range(2)]
-        oracle[name] = (feats, opipe.pair_detections_computed(inps, feats, hp, C, synth.P2,
-                                                             synth.IMAGE_WH, 1024))
     tols = (1e-4, 1e-3, 1e-2, 5e-2)
+    oracle = []          # per pair: {arithmetic: (feats, detections)}
+    for k, (seq, frames) in enumerate(FREE_RUNNING_PAIRS):
+        pts = [synth.lidar_frame(seq, f) for f in frames]
+        imgs = [synth.image_frame(seq, f) for f in frames]
+        inps = [opipe.frame_inputs(p, C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2, synth.IMAGE_WH)
+                for p in pts]
+        row = {}
+        for name in (('f32', 'exact') if k == 0 else ('exact',)):
+            if name == 'exact':
+                with tfops.exact_sums():
+                    feats = [opipe.extract(inps[j]['bev'], imgs[j], w['bev_params'], w['img_params'],
+                                           C['img_dims']) for j in range(2)]
+            else:
+                feats = [opipe.extract(inps[j]['bev'], imgs[j], w['bev_params'], w['img_params'],
+                                       C['img_dims']) for j in range(2)]
+            row[name] = (feats if k == 0 else None,
+                         opipe.pair_detections_computed(inps, feats, hp, C, synth.P2, synth.IMAGE_WH, 1024))
+        oracle.append(row)
 
     def agreement(got_top, got_rec, ref):
         n_ref = len(ref['det_idx'])
         top, _ = _matched(got_top, ref['top_anchors'], 1e-3)
         fr = [_matched(got_rec[:, :8], ref['records'][:n_ref, :8], t) for t in tols]
-        return dict(proposals=round(top, 4), n_det=len(got_rec), n_det_ref=n_ref,
-                    det=[round(f[0], 4) for f in fr], missed_5e2=fr[-1][1])
+        return dict(proposals=round(top / max(len(ref['top_anchors']), 1), 4), n_det=len(got_rec), n_det_ref=n_ref,
+                    hits=[f[0] for f in fr], det=[round(f[0] / max(n_ref, 1), 4) for f in fr], missed_5e2=fr[-1][1])
+
+    def pooled(frames_rows):
+        n = sum(a['n_det_ref'] for a in frames_rows)
+        return [round(sum(a['hits'][t] for a in frames_rows) / max(n, 1), 4) for t in range(len(tols))], n
 
     table = {}
-    # the floor: the float32 oracle against the exact one
-    table['oracle f32'] = {'exact': [agreement(oracle['f32'][1][f]['top_anchors'],
-                                               oracle['f32'][1][f]['records'][:len(oracle['f32'][1][f]['det_idx'])],
-                                               oracle['exact'][1][f]) for f in range(2)]}
+    # the floor: the float32 oracle against the exact one (first pair)
+    o32, oex = oracle[0]['f32'][1], oracle[0]['exact'][1]
+    table['oracle f32'] = {'exact': [agreement(o32[f]['top_anchors'], o32[f]['records'][:len(o32[f]['det_idx'])], oex[f])
+                                     for f in range(2)]}
     default_mode = None
     for label, mode in FREE_RUNNING_MODES:
         out = str(tmp_path / ('fr_%s.npz' % mode))
-        r = subprocess.run([sys.executable, '-c', _CHILD % root, out],
+        r = subprocess.run([sys.executable, '-c', _CHILD % (root, FREE_RUNNING_PAIRS), out],
                            env=dict(os.environ, DODT_CONV_WINO=mode), capture_output=True, text=True,
-                           timeout=600)
+                           timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         got = np.load(out)
         assert int(got['mode']) == int(mode)
-        row = {}
-        for base in ('f32', 'exact'):
-            row[base] = [agreement(got['top%d' % f], got['rec%d' % f], oracle[base][1][f])
-                         for f in range(2)]
+        row = {'f32': [agreement(got['p0_top%d' % f], got['p0_rec%d' % f], oracle[0]['f32'][1][f]) for f in range(2)],
+               'exact': [agreement(got['p%d_top%d' % (k, f)], got['p%d_rec%d' % (k, f)], oracle[k]['exact'][1][f])
+                         for k in range(len(FREE_RUNNING_PAIRS)) for f in range(2)]}
+        row['exact_pooled'], row['n_pooled'] = pooled(row['exact'])
         # error of the stack's output and of the 7x7 crops taken from it, against both oracles'
-        # feature maps (of the map's scale): the fp32 crop bar of tests/test_gpu_pipeline.py is 1e-5
+        # feature maps (of the map's scale; first pair): the fp32 crop bar of tests/test_gpu_pipeline.py is 1e-5
         for base in ('f32', 'exact'):
             ferr, cerr = [], []
             for f in range(2):
-                ref_map = oracle[base][0][f][0]
+                ref_map = oracle[0][base][0][f][0]
                 sc = np.abs(ref_map).max()
                 ferr.append(float(np.abs(got['feat%d' % f] - ref_map).max() / sc))
                 want = tfops.crop_and_resize(ref_map, got['top_bev%d' % f], 7, 7)
                 cerr.append(float(np.abs(got['bev_rois%d' % f] - want).max() / sc))
             row[base + '_feat_err'] = [float('%.3g' % v) for v in ferr]
             row[base + '_crop_err'] = [float('%.3g' % v) for v in cerr]
-        # where the detections that miss 5e-2 against the f32 oracle diverge
+        # where the detections that miss 5e-2 against the f32 oracle diverge (first pair)
         for f in range(2):
-            ref = oracle['f32'][1][f]
+            ref = oracle[0]['f32'][1][f]
             for i in row['f32'][f]['missed_5e2']:
                 rr = ref['records'][i, :8]
-                d = np.abs(got['rec%d' % f][:, :8] - rr) / (1.0 + 0.1 * np.abs(rr))
+                d = np.abs(got['p0_rec%d' % f][:, :8] - rr) / (1.0 + 0.1 * np.abs(rr))
                 j = int(np.argmin(d[:, :3].max(axis=1)))      # nearest device detection by position
                 cols = ['x', 'y', 'z', 'l', 'w', 'h', 'ry', 'score']
                 worst = int(np.argmax(d[j]))
@@ -452,30 +463,26 @@ def test_pair_free_running_by_conv_mode(tmp_path):
         table[label] = row
         if int(mode) == int(device.default_context().lib.dodt_conv_mode()):
             default_mode = label
-    print('\nfree-running agreement, detections within 1e-4 / 1e-3 / 1e-2 / 5e-2 (frame 0 | frame 1)')
-    for label, row in table.items():
-        for base in row:
-            if base.endswith('_err'):
-                continue
-            print('  %-12s vs %-5s: %s' % (label, base, ' | '.join(
-                'prop %.3f det %d/%d %s' % (a['proposals'], a['n_det'], a['n_det_ref'],
-                                            ' '.join('%.2f' % v for v in a['det'])) for a in row[base])))
-        if 'f32_feat_err' in row:
-            print('  %-12s feature-map / crop error vs f32: %s / %s; vs exact: %s / %s' % (
-                label, row['f32_feat_err'], row['f32_crop_err'], row['exact_feat_err'], row['exact_crop_err']))
+    print('\nfree-running agreement with the exact oracle, detections within 1e-4 / 1e-3 / 1e-2 / 5e-2, pooled over '
+          '%d frames' % (2 * len(FREE_RUNNING_PAIRS)))
+    print('  %-12s (first pair only, %d detections): %s' % ('oracle f32', sum(a['n_det_ref'] for a in table['oracle f32']['exact']),
+                                                           pooled(table['oracle f32']['exact'])[0]))
+    for label, _ in FREE_RUNNING_MODES:
+        row = table[label]
+        print('  %-12s %s over %d detections; per frame at 1e-3: %s' % (
+            label, row['exact_pooled'], row['n_pooled'], ' '.join('%.2f' % a['det'][1] for a in row['exact'])))
+        print('  %-12s feature-map / crop error vs f32: %s / %s; vs exact: %s / %s' % (
+            label, row['f32_feat_err'], row['f32_crop_err'], row['exact_feat_err'], row['exact_crop_err']))
     out_dir = os.path.join(root, 'gpurun_out')
     if os.path.isdir(out_dir):
         json.dump(table, open(os.path.join(out_dir, 'free_running.json'), 'w'), indent=1)
 
-    def at(label, base, k):      # mean over the two frames of the agreement at tols[k]
-        return float(np.mean([a['det'][k] for a in table[label][base]]))
     assert default_mode is not None, 'the library default is not one of the tested forms'
     for label, _ in FREE_RUNNING_MODES:
-        for base in ('f32', 'exact'):
-            for a in table[label][base]:
-                assert a['proposals'] >= 0.95, (label, base, a)
-                assert abs(a['n_det'] - a['n_det_ref']) <= max(2, 0.1 * a['n_det_ref']), (label, base, a)
-        assert at(label, 'exact', 3) >= at('direct', 'exact', 3) - 0.05, label
-    # the rule of DESIGN.md 5.0
-    assert at(default_mode, 'exact', 1) >= at('direct', 'exact', 1) - 0.10, \
-        (default_mode, at(default_mode, 'exact', 1), at('direct', 'exact', 1))
+        for a in table[label]['exact'] + table[label]['f32']:
+            assert a['proposals'] >= 0.95, (label, a)
+            assert abs(a['n_det'] - a['n_det_ref']) <= max(2, 0.1 * a['n_det_ref']), (label, a)
+        assert table[label]['exact_pooled'][3] >= table['direct']['exact_pooled'][3] - 0.05, label
+    # the rule of DESIGN.md 5.0, on the pooled fractions
+    assert table[default_mode]['exact_pooled'][1] >= table['direct']['exact_pooled'][1] - 0.10, \
+        (default_mode, table[default_mode]['exact_pooled'], table['direct']['exact_pooled'])
