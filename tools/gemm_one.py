@@ -12,7 +12,8 @@ M, K, N, reps = (int(v) for v in (sys.argv[1:5] + ['1024', '2048', '2048', '10']
 ctx = device.default_context()
 rng = np.random.default_rng(0)
 x = ctx.array(rng.normal(size=(M, K)).astype(np.float32))
-fc = ops.FullyConnected(ctx, rng.normal(size=(K, N)).astype(np.float32), np.zeros(N, np.float32), True)
+fc = ops.FullyConnected(ctx, rng.normal(size=(K, N)).astype(np.float32), np.zeros(N, np.float32), True,
+                        dtype=os.environ.get('DODT_GEMM_ONE_DTYPE', 'f32'))
 y = ctx.empty((M, N), np.float32)
 for _ in range(reps):
     fc.forward(x, M, y)
