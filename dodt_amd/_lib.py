@@ -127,6 +127,10 @@ SIGNATURES = {
     'dodt_fc_forward': (_i, [_vp, _vp, _pf, _pf, _i, _i, _pi32, _pf, _i]),
     'dodt_fc_forward_split': (_i, [_vp, _vp, _pf, _i, _i, _pi32, _i, C.POINTER(_i), C.POINTER(_vp)]),
     'dodt_fc_flops': (_d, [_vp, _i]),
+    'dodt_fc_bf16_row_elems': (_i, [_vp]),
+    'dodt_fc_forward_bf16': (_i, [_vp, _vp, _vp, _i, _i, _pi32, _vp, _i, _i]),
+    'dodt_fc_forward_split_bf16': (_i, [_vp, _vp, _vp, _i, _i, _pi32, _i, C.POINTER(_i), C.POINTER(_vp)]),
+    'dodt_rows_to_bf16': (_i, [_vp, _pf, _pf, _i, _pi32, _i, _i, _vp, _i]),
     'dodt_nms': (_i, [_vp, _pf, _pf, _i, _pi32, _i, _f, _pi32, _pi32]),
     'dodt_offset_to_anchor': (_i, [_vp, _pf, _pf, _i, _pi32, _pf]),
     'dodt_softmax_fg': (_i, [_vp, _pf, _i, _pi32, _pf]),

@@ -2,6 +2,8 @@
 (avod/core/avod_fc_layers/fusion_fc_layers.py:94-180 with fusion_method 'mean') and the
 correlation-offsets head built from the same stack
 (avod/builders/avod_corr_layers_builder.py:126-169)."""
+import os
+
 import numpy as np
 
 from dodt_amd import ops
@@ -50,11 +52,22 @@ class EarlyFusionFcLayers(object):
                 fused.close()
         self.width = max(l.N for l in self.hidden)
         self.ctx = ctx
+        # bf16 heads keep their hidden activations as bf16 rows in HBM when every layer has that path
+        # (csrc/gemm.hip: fc_bf16_dma_kernel; DODT_FC_BF16_ROWS=0: float32 activations, rounded on every load)
+        self.bf16_rows = dtype == 'bf16' and os.environ.get('DODT_FC_BF16_ROWS', '1') != '0' and \
+            all(l.bf16_row_elems() > 0 for l in self.hidden) and \
+            (self.fused_out.bf16_row_elems() > 0 if self.fused_out is not None
+             else all(l.bf16_row_elems() > 0 for l in self.outputs))
+        self.in_ld16 = self.hidden[0].bf16_row_elems() if self.bf16_rows else 0
 
     def make_scratch(self, n_max):
         """Ping-pong hidden activations + the fused input rows; one set per concurrent stream."""
-        return [self.ctx.empty((n_max, self.width), np.float32) for _ in range(2)] + \
-               [self.ctx.zeros((n_max, self.in_ld), np.float32)]
+        s = [self.ctx.empty((n_max, self.width), np.float32) for _ in range(2)] + \
+            [self.ctx.zeros((n_max, self.in_ld), np.float32)]
+        if self.bf16_rows:      # [3], [4]: ping-pong bf16 activations, [5]: the first layer's bf16 rows
+            s += [self.ctx.zeros((n_max, self.width), np.uint16) for _ in range(2)] + \
+                 [self.ctx.zeros((n_max, self.in_ld16), np.uint16)]
+        return s
 
     def forward(self, ctx, d_rois, d_rois2, n, d_n, d_outs, scratch):
         """d_rois: n rows of `in_ld` floats, the flattened (h,w,c) crop in front and zeros behind it
@@ -64,6 +77,20 @@ class EarlyFusionFcLayers(object):
         ldx = self._row_floats(d_rois, n, 'd_rois')
         if x2 is not None and self._row_floats(x2, n, 'd_rois2') != ldx:
             raise ValueError('d_rois and d_rois2 must have the same row layout')
+        if self.bf16_rows and len(scratch) > 5:
+            # bf16((a + b) / 2) [or bf16(a)] as rows of in_ld16 elements with a zero tail, then bf16 rows all the way
+            ops.rows_to_bf16(ctx, x, x2, n, d_n, self.in_k, ldx, scratch[5], self.in_ld16)
+            x16, ld16 = scratch[5], self.in_ld16
+            for i, l in enumerate(self.hidden):
+                y16 = scratch[3 + (i & 1)]
+                l.forward_bf16(x16, n, y16, ldx=ld16, ldy=self.width, d_m=d_n, y_bf16=True, ctx=ctx)
+                x16, ld16 = y16, self.width
+            if self.fused_out is not None:
+                self.fused_out.forward_split_bf16(x16, n, d_outs, [l.N for l in self.outputs], ldx=ld16, d_m=d_n, ctx=ctx)
+            else:
+                for l, d_y in zip(self.outputs, d_outs):
+                    l.forward_bf16(x16, n, d_y, ldx=ld16, d_m=d_n, y_bf16=False, ctx=ctx)
+            return
         first = self.hidden[0]
         if ldx != self.in_ld:          # packed rows of in_k floats, in_k % 32 != 0
             if self._packed_first is None:

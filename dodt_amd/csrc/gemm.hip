@@ -514,6 +514,186 @@ int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
     return DODT_OK;
 }
 
+// ---- bf16 heads, round 4: bf16 activations in HBM, both operands by LDS-DMA ---------------------------------
+// fc_mfma_kernel's bf16 instantiation reads float32 x, rounds it on its way into LDS (a register-staged ds_write
+// pass with the conversions on the vector ALU) and prefetches two 32-k stages ahead: at the heads' M = 1024 a stage is
+// ~130 matrix cycles per SIMD against > 1000 cycles of load latency, so the K loop waits for memory: 32 us at
+// N = K = 2048 with an intercept of ~25 us per launch (M = 1024 / 2048 / 4096: 32 / 38 / 60 us).  Here the hidden
+// activations of a head stay bf16 in HBM -- the layer that produces them rounds them (to nearest even) in its
+// epilogue, which is the same rounding the next layer's load applied, so the arithmetic of oracle/heads.py's bf16
+// restatement is unchanged -- and a stage (64 k: x 64 rows x 128 B, weights 128 columns x 128 B, 24 KB) travels
+// global -> LDS by buffer_load_dwordx4 ... lds with scalar operands, three stages in a ring, two workgroups per CU
+// (six stages in flight per CU ~ what the L2 -> LDS fill rate of ~50 B/clk/CU takes).  Both images are unpadded
+// with the 16-byte k-slots of row / column r XOR-swizzled by (r >> 1) & 7 (x: on the source address; weights:
+// pre-swizzled on the host, a stage image is one contiguous 16 KB block): conflict-free ds_read_b128 fragments.
+// 64 x 128 tiles, wave = 32 x 64 (one x fragment, two weight fragments, two v_mfma_f32_32x32x16_bf16 per 16 k).
+// Needs x rows of >= Kd = ceil(K / 64) 64 bf16 whose tail beyond K is zero, 16-byte aligned, N % 128 == 0.
+// BK = k per stage: 64 (24 KB stages, 72 KB: the fastest layer alone) or 32 (12 KB stages, 36 KB: fits into the
+// 41 KB two resident bf16 conv workgroups leave of a CU's LDS, like fc_mfma_kernel's 32-k form did).  A row /
+// column of a stage image is BK / 8 slots of 16 bytes; slot s of row r sits in slot s ^ ((r / (16 / S)) & (S - 1)),
+// S = BK / 8: 16 consecutive rows then cover the 16 bank columns for every s.
+constexpr int kBfBM = 64, kBfBN = 128, kBfStages = 3;
+__host__ __device__ constexpr int bf_swz(int r, int S) { return (r / (16 / S)) & (S - 1); }
+
+template <bool YBF16, int BK>
+__global__ void __launch_bounds__(256, 2)
+fc_bf16_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    using dodt::i32x4_t;
+    using dodt::kOob;
+    using dodt::make_rsrc;
+    constexpr int S = BK / 8;                                  // 16-byte slots per row of an image
+    constexpr int kXBytes = kBfBM * BK * 2, kWBytes = kBfBN * BK * 2, kStage = kXBytes + kWBytes;
+    constexpr int kXPieces = kXBytes / 1024 / 4, kWPieces = kWBytes / 1024 / 4;   // 1 KB copies per wave and stage
+    constexpr int kPerStage = kXPieces + kWPieces;
+    constexpr int kRowsPerPiece = 1024 / (BK * 2);
+    constexpr int NQ = BK / 16;                                // MFMA k-steps per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // XCD-aware tile order (as fc_dma_kernel): XCD j takes the j-th eighth of the tile list, n fastest
+    const int T = tiles_m * tiles_n;
+    int tile = blockIdx.x;
+    if (T % 8 == 0) tile = (int)(blockIdx.x % 8) * (T / 8) + (int)(blockIdx.x / 8);
+    const int mt = tile / tiles_n, nt0 = tile % tiles_n;
+    const int m0 = mt * kBfBM;
+    const int M = a.d_m ? min(*a.d_m, a.M) : a.M;
+    if (m0 >= M) return;
+    const int nstages = a.Kp / BK;          // (Kp: K rounded up to 64 for this kernel)
+    const int rows = min(M - m0, kBfBM);
+    const unsigned short* x16 = reinterpret_cast<const unsigned short*>(a.x);
+    const i32x4_t x_rsrc = make_rsrc(x16 + (size_t)m0 * a.ldx, (unsigned)(((size_t)(rows - 1) * a.ldx + a.Kp) * 2));
+    const char* wblk = reinterpret_cast<const char*>(a.w) + (size_t)nt0 * nstages * kWBytes;
+    const i32x4_t w_rsrc = make_rsrc(wblk, (unsigned)((size_t)nstages * kWBytes));
+    // copy plan: per stage the x image (rows of BK bf16) and the weight image (pre-swizzled, contiguous) in 1 KB
+    // pieces; wave w issues pieces w, w + 4, ...
+    int x_off[kXPieces];
+#pragma unroll
+    for (int k = 0; k < kXPieces; ++k) {
+        const int row = (wave + 4 * k) * kRowsPerPiece + lane / S, slot = (lane % S) ^ bf_swz(row, S);
+        x_off[k] = row < rows ? (row * a.ldx + slot * 8) * 2 : kOob;
+    }
+    const int w_off = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    auto issue_one = [&](int st, int buf, int n) {
+        const unsigned sX = lds0 + (unsigned)(buf * kStage);
+        if (n < kXPieces) dodt::blds16s(x_rsrc, x_off[n < kXPieces ? n : 0], st * (BK * 2), sX + (unsigned)(wave + 4 * n) * 1024);
+        else dodt::blds16s(w_rsrc, w_off, st * kWBytes + (wave + 4 * (n - kXPieces)) * 1024,
+                           sX + kXBytes + (unsigned)(wave + 4 * (n - kXPieces)) * 1024);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    // fragment addresses inside a stage (bytes): x row wm 32 + li, weight columns wn 64 + nt 32 + li; both swizzles
+    // depend on li only (the bases are multiples of 32), so the k-steps share their slot offsets
+    const int sw = bf_swz(li, S);
+    int so[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) so[q] = ((2 * q + lh) ^ sw) * 16;
+    const int x_base = (wm * 32 + li) * (BK * 2);
+    const int w_base = kXBytes + (wn * 64 + li) * (BK * 2);
+    auto stage = [&](auto bufc, int st) {
+        constexpr int BUF = decltype(bufc)::value;
+        // stage st has landed once all but the copies of stage st + 1 are done
+        if (st + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0f70 | kPerStage);   // vmcnt(kPerStage)
+        else __builtin_amdgcn_s_waitcnt(0x0f70);                                  // vmcnt(0)
+        __builtin_amdgcn_s_barrier();     // ... for every wave; buffer (BUF + 2) % 3 is free
+        const bool more = st + 2 < nstages;
+        const char* sS = reinterpret_cast<const char*>(smem) + BUF * kStage;
+        f32x4 xf[NQ], wf[NQ][2];
+        auto read_q = [&](int q) {
+            xf[q] = *reinterpret_cast<const f32x4*>(sS + x_base + so[q]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                wf[q][nt] = *reinterpret_cast<const f32x4*>(sS + w_base + nt * 32 * (BK * 2) + so[q]);
+        };
+        read_q(0);
+        read_q(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 2 < NQ) read_q(q + 2);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xf[q]),
+                                                                  __builtin_bit_cast(bf16x8, wf[q][nt]), acc[nt], 0, 0, 0);
+            if (more) {
+                // the copies of stage st + 2 spread over the k-steps
+                constexpr int kPerQ = (kPerStage + NQ - 1) / NQ;
+#pragma unroll
+                for (int n = q * kPerQ; n < (q + 1) * kPerQ && n < kPerStage; ++n) issue_one(st + 2, (BUF + 2) % kBfStages, n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto issue = [&](int st, int buf) {
+#pragma unroll
+        for (int n = 0; n < kPerStage; ++n) issue_one(st, buf, n);
+    };
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+    for (int st = 0; st < nstages; st += 3) {
+        stage(std::integral_constant<int, 0>{}, st);
+        if (st + 1 < nstages) stage(std::integral_constant<int, 1>{}, st + 1);
+        if (st + 2 < nstages) stage(std::integral_constant<int, 2>{}, st + 2);
+    }
+    // epilogue: bias + activation; lane = feature, registers = samples; bf16 output: round to nearest even
+    const int n0 = nt0 * kBfBN;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + li;
+        const float b = a.bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < M && n < a.N) {
+                float v = acc[nt][r] + b;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if constexpr (YBF16)
+                    reinterpret_cast<unsigned short*>(a.y)[(size_t)m * a.ldy + n] =
+                        (unsigned short)(__builtin_bit_cast(unsigned, pack_bf16(v, 0.0f)) & 0xffffu);
+                else
+                    a.y[(size_t)m * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+int launch_fc_bf16_dma(hipStream_t s, const GemmArgs& a, int Npad, bool y_bf16, int bk) {
+    const int tiles_m = dodt::ceil_div(a.M, kBfBM), tiles_n = Npad / kBfBN;
+    const size_t lds = (size_t)kBfStages * (kBfBM + kBfBN) * bk * 2;
+    auto go = [&](auto kernel) -> hipError_t {
+        static std::mutex mu;
+        static std::set<const void*> prepared;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!prepared.count(reinterpret_cast<const void*>(kernel))) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                prepared.insert(reinterpret_cast<const void*>(kernel));
+            }
+        }
+        hipLaunchKernelGGL(kernel, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (bk == 64) e = y_bf16 ? go(&fc_bf16_dma_kernel<true, 64>) : go(&fc_bf16_dma_kernel<false, 64>);
+    else e = y_bf16 ? go(&fc_bf16_dma_kernel<true, 32>) : go(&fc_bf16_dma_kernel<false, 32>);
+    DODT_HIP_CHECK(e);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+// stage depth of fc_bf16_dma_kernel in this process (DODT_FC_BF16_DMA_BK = 32 | 64; the weights are blocked for it)
+int bf16_dma_bk() {
+    static const int bk = getenv("DODT_FC_BF16_DMA_BK") && atoi(getenv("DODT_FC_BF16_DMA_BK")) == 64 ? 64 : 32;
+    return bk;
+}
+
 // ---- the skinny layers (N <= 32: the heads' output layers, 2048 -> 2 / 10 / 2 / 3, and the RPN's
 //      256 -> 2 / 6) ---------------------------------------------------------------------------------
 // On the tiled kernels such a layer is ceil(M / 128) workgroups that each walk all of K: 8 workgroups
@@ -538,9 +718,11 @@ __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF16>
+// (XB16: x is already bf16 in memory -- the bf16 heads' hidden activations --, ldx in elements)
+template <bool BF16, bool XB16 = false>
 __global__ void __launch_bounds__(512)
 fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
+    static_assert(BF16 || !XB16, "bf16 rows feed the bf16 arithmetic only");
     __shared__ f32x4 s_part[8][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -549,6 +731,7 @@ fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
     if (m0 >= M) return;
     // A operand: lane (g, i) holds sample m0 + i at k-slot g; a 16-byte load covers the slot's four k of a step
     const float* xr = a.x + (size_t)min(m0 + i, M - 1) * a.ldx + 4 * g;
+    const unsigned short* xr16 = reinterpret_cast<const unsigned short*>(a.x) + (size_t)min(m0 + i, M - 1) * a.ldx + 4 * g;
     const int steps = a.K / 16;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
@@ -563,14 +746,20 @@ fc_skinny_kernel(const GemmArgs a, const SplitOut so) {
                 const int j = j0 + 8 * u;
                 const bool ok = j < steps;
                 const int jj = ok ? j : wave;
-                xv[u] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+                if constexpr (XB16) {      // 8 bytes = the slot's four k, already rounded
+                    const f32x2 x2 = *reinterpret_cast<const f32x2*>(xr16 + 16 * jj);
+                    xv[u] = f32x4{x2[0], x2[1], 0.f, 0.f};
+                } else {
+                    xv[u] = *reinterpret_cast<const f32x4*>(xr + 16 * jj);
+                }
                 const f32x2 z = {0.f, 0.f};
                 wa[u] = ok ? w2[(size_t)jj * 128] : z;           // a step = 2 h-planes of 32 x 16 bytes
                 wb[u] = ok ? w2[(size_t)jj * 128 + 32] : z;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const f32x2 xb = {pack_bf16(xv[u][0], xv[u][1]), pack_bf16(xv[u][2], xv[u][3])};
+                const f32x2 xb = XB16 ? f32x2{xv[u][0], xv[u][1]}
+                                      : f32x2{pack_bf16(xv[u][0], xv[u][1]), pack_bf16(xv[u][2], xv[u][3])};
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, xb),
                                                                  __builtin_bit_cast(s16x4, wa[u]), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, xb),
@@ -671,8 +860,9 @@ bool skinny_ok(int Npad, int K, const GemmArgs& a) {
     return on && Npad == 32 && K % 16 == 0 && a.ldx % 4 == 0 && (size_t)a.x % 16 == 0 && !a.x2;
 }
 
-int launch_fc_skinny(hipStream_t s, const GemmArgs& a, const SplitOut& so, bool bf16) {
-    if (bf16) hipLaunchKernelGGL(fc_skinny_kernel<true>, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
+int launch_fc_skinny(hipStream_t s, const GemmArgs& a, const SplitOut& so, bool bf16, bool x_bf16 = false) {
+    if (x_bf16) hipLaunchKernelGGL((fc_skinny_kernel<true, true>), dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
+    else if (bf16) hipLaunchKernelGGL(fc_skinny_kernel<true>, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
     else hipLaunchKernelGGL(fc_skinny_kernel<false>, dim3(dodt::ceil_div(a.M, 16)), dim3(512), 0, s, a, so);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
@@ -712,6 +902,50 @@ extern "C" int dodt_mean_fusion(dodt_ctx* ctx, const float* d_a, const float* d_
     return DODT_OK;
 }
 
+// The input rows of a bf16 head: out[r][0 .. row_floats) = bf16((a[r] + b[r]) / 2) (or bf16(a[r]) without b),
+// out[r][row_floats .. out_ld) = 0; a / b rows in_ld floats apart, one lane per four elements.
+namespace {
+__global__ void __launch_bounds__(256)
+rows_to_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows, const int* __restrict__ d_n,
+                    int row_floats, int in_ld, unsigned short* __restrict__ out, int out_ld) {
+    const int lim = d_n ? min(*d_n, rows) : rows;
+    const int q4 = out_ld / 4;
+    const long long total = (long long)lim * q4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / q4), c = (int)(i - (long long)r * q4) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.0f;
+            if (c + e < row_floats) {
+                t = a[(size_t)r * in_ld + c + e];
+                if (b) t = (t + b[(size_t)r * in_ld + c + e]) / 2.0f;
+            }
+            v[e] = t;
+        }
+        f32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        *reinterpret_cast<f32x2*>(out + (size_t)r * out_ld + c) = o;
+    }
+}
+}  // namespace
+
+extern "C" int dodt_rows_to_bf16(dodt_ctx* ctx, const float* d_a, const float* d_b, int rows, const int32_t* d_n,
+                                 int row_floats, int in_ld, void* d_out_bf16, int out_ld) {
+    DODT_REQUIRE(ctx && d_a && d_out_bf16, "dodt_rows_to_bf16: NULL argument");
+    DODT_REQUIRE(rows >= 0 && row_floats >= 1 && in_ld >= row_floats && out_ld >= row_floats && out_ld % 4 == 0,
+                 "dodt_rows_to_bf16: rows of %d floats, %d apart, into rows of %d bf16 (a multiple of 4)", row_floats,
+                 in_ld, out_ld);
+    DODT_REQUIRE((size_t)d_out_bf16 % 8 == 0, "dodt_rows_to_bf16: 8-byte aligned output");
+    if (rows == 0) return DODT_OK;
+    const long long total = (long long)rows * (out_ld / 4);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_a, d_b, rows, d_n, row_floats,
+                       in_ld, reinterpret_cast<unsigned short*>(d_out_bf16), out_ld);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
 struct dodt_fc {
     dodt_ctx* ctx = nullptr;
     int K = 0, Kp = 0, N = 0, Npad = 0, BN = 0, relu = 0;
@@ -719,6 +953,9 @@ struct dodt_fc {
     float* d_w = nullptr;
     float* d_b = nullptr;
     float* d_w_plain = nullptr;   // [K][N] as given (bf16 layers: rounded), for K <= kSmallK
+    void* d_w_dma = nullptr;      // bf16 layers with N % 128 == 0: stage images for fc_bf16_dma_kernel
+    int Kd = 0;                   //   ... of K rounded up to 64
+    int dma_bk = 0;               //   ... blocked for stages of this many k
 };
 
 extern "C" {
@@ -768,6 +1005,27 @@ int dodt_fc_create_ex(dodt_ctx* ctx, int K, int N, const float* w, const float* 
                                   hipMemcpyHostToDevice, ctx->stream));
     DODT_HIP_CHECK(hipMemcpyAsync(f->d_b, b.data(), b.size() * sizeof(float),
                                   hipMemcpyHostToDevice, ctx->stream));
+    if (bf16 && N % kBfBN == 0 && K >= 128) {
+        // fc_bf16_dma_kernel's weights: [n-tile of 128][stage of BK k][column c][slot p] 16 bytes = 8 bf16, slot p
+        // holding k = BK stage + 8 (p ^ swz(c)) .. + 7 (the conflict-free LDS image of a stage, contiguous)
+        const int BK = bf16_dma_bk(), S = BK / 8;
+        f->Kd = (int)dodt::align_up((size_t)K, (size_t)64);
+        f->dma_bk = BK;
+        const int ns = f->Kd / BK;
+        std::vector<uint16_t> img((size_t)(N / kBfBN) * ns * kBfBN * BK, 0);
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < N; ++n) {
+                const int t = n / kBfBN, c = n % kBfBN, st = k / BK, kk = k % BK;
+                const int slot = (kk / 8) ^ bf_swz(c, S);
+                img[((((size_t)t * ns + st) * kBfBN + c) * S + slot) * 8 + kk % 8] = dodt::float_to_bf16(w[(size_t)k * N + n]);
+            }
+        if (hipMalloc(&f->d_w_dma, img.size() * sizeof(uint16_t)) != hipSuccess) {
+            dodt::set_error("dodt_fc_create: hipMalloc failed");
+            dodt_fc_destroy(f);
+            return DODT_ERR_HIP;
+        }
+        DODT_HIP_CHECK(hipMemcpy(f->d_w_dma, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     std::vector<float> plain;
     if (K <= kSmallK && N % 4 == 0) {
         plain.assign(w, w + (size_t)K * N);
@@ -791,6 +1049,7 @@ int dodt_fc_destroy(dodt_fc* f) {
     if (f->d_w) (void)hipFree(f->d_w);
     if (f->d_b) (void)hipFree(f->d_b);
     if (f->d_w_plain) (void)hipFree(f->d_w_plain);
+    if (f->d_w_dma) (void)hipFree(f->d_w_dma);
     delete f;
     return DODT_OK;
 }
@@ -878,6 +1137,72 @@ int dodt_fc_forward_split(dodt_fc* f, dodt_ctx* ctx, const float* d_x, int ldx, 
     }
     if (M == 0) return DODT_OK;
     return launch_fc_skinny((ctx ? ctx : f->ctx)->stream, a, so, f->bf16);
+}
+
+int dodt_fc_bf16_row_elems(const dodt_fc* f) {
+    // bf16 elements an input row of dodt_fc_forward_bf16 must hold (zeros beyond K): 0 = the layer has no such path
+    if (!f || !f->bf16) return 0;
+    if (f->d_w_dma) return f->Kd;
+    return (f->Npad == 32 && f->K % 16 == 0) ? f->K : 0;
+}
+
+int dodt_fc_forward_bf16(dodt_fc* f, dodt_ctx* ctx, const void* d_x_bf16, int ldx, int M, const int32_t* d_m,
+                         void* d_y, int ldy, int y_bf16) {
+    DODT_REQUIRE(f && d_x_bf16 && d_y, "dodt_fc_forward_bf16: NULL argument");
+    DODT_REQUIRE(f->bf16, "dodt_fc_forward_bf16: the layer was not created with DODT_FC_BF16");
+    DODT_REQUIRE(M >= 0 && ldy >= f->N, "dodt_fc_forward_bf16: bad strides");
+    if (M == 0) return DODT_OK;
+    GemmArgs a;
+    a.x = reinterpret_cast<const float*>(d_x_bf16); a.x2 = nullptr; a.bias = f->d_b; a.y = reinterpret_cast<float*>(d_y);
+    a.M = M; a.K = f->K; a.N = f->N; a.ldx = ldx; a.ldy = ldy; a.relu = f->relu; a.d_m = d_m;
+    hipStream_t s = (ctx ? ctx : f->ctx)->stream;
+    if (f->d_w_dma) {
+        DODT_REQUIRE(ldx >= f->Kd && ldx % 8 == 0 && (size_t)d_x_bf16 % 16 == 0,
+                     "dodt_fc_forward_bf16: rows of >= %d bf16 (zeros beyond K = %d), 16-byte aligned", f->Kd, f->K);
+        DODT_REQUIRE((size_t)M * ldx * 2 < (1ull << 31), "dodt_fc_forward_bf16: x block beyond 2 GB");
+        a.w = reinterpret_cast<const float*>(f->d_w_dma);
+        a.Kp = f->Kd;
+        return launch_fc_bf16_dma(s, a, f->Npad, y_bf16 != 0, f->dma_bk);
+    }
+    if (f->Npad == 32 && f->K % 16 == 0 && ldx % 4 == 0 && (size_t)d_x_bf16 % 8 == 0 && !y_bf16) {
+        DODT_REQUIRE(ldx >= f->K, "dodt_fc_forward_bf16: bad strides");
+        a.w = f->d_w; a.Kp = f->Kp;
+        float* y = reinterpret_cast<float*>(d_y);
+        SplitOut so = {{y, y, y}, {f->N, f->N, f->N}, {ldy, ldy, ldy}};
+        return launch_fc_skinny(s, a, so, true, true);
+    }
+    dodt::set_error("dodt_fc_forward_bf16: layers with N %% 128 == 0 and K >= 128, or N <= 32 and K %% 16 == 0 with "
+                    "float32 output, only (K = %d, N = %d)", f->K, f->N);
+    return DODT_ERR_UNSUPPORTED;
+}
+
+int dodt_fc_forward_split_bf16(dodt_fc* f, dodt_ctx* ctx, const void* d_x_bf16, int ldx, int M, const int32_t* d_m,
+                               int parts, const int* widths, float* const* d_ys) {
+    DODT_REQUIRE(f && d_x_bf16 && widths && d_ys, "dodt_fc_forward_split_bf16: NULL argument");
+    DODT_REQUIRE(f->bf16, "dodt_fc_forward_split_bf16: the layer was not created with DODT_FC_BF16");
+    DODT_REQUIRE(parts >= 1 && parts <= 3, "dodt_fc_forward_split_bf16: %d parts (1..3)", parts);
+    DODT_REQUIRE(M >= 0 && ldx >= f->K, "dodt_fc_forward_split_bf16: bad strides");
+    GemmArgs a;
+    a.x = reinterpret_cast<const float*>(d_x_bf16); a.x2 = nullptr; a.w = f->d_w; a.bias = f->d_b; a.y = nullptr;
+    a.M = M; a.K = f->K; a.Kp = f->Kp; a.N = f->N; a.ldx = ldx; a.ldy = 0; a.relu = f->relu;
+    a.d_m = d_m;
+    SplitOut so;
+    int end = 0;
+    for (int p = 0; p < 3; ++p) {
+        const int q = p < parts ? p : parts - 1;
+        DODT_REQUIRE(widths[q] >= 1 && d_ys[q], "dodt_fc_forward_split_bf16: part %d is empty", q);
+        if (p < parts) end += widths[p];
+        so.y[p] = d_ys[q];
+        so.n_end[p] = p < parts ? end : f->N + 1;
+        so.ld[p] = widths[q];
+    }
+    DODT_REQUIRE(end == f->N, "dodt_fc_forward_split_bf16: the parts have %d columns, the layer %d", end, f->N);
+    if (!(f->Npad == 32 && f->K % 16 == 0 && ldx % 4 == 0 && (size_t)d_x_bf16 % 8 == 0)) {
+        dodt::set_error("dodt_fc_forward_split_bf16: layers with N <= 32, K %% 16 == 0 and 8-byte aligned rows only");
+        return DODT_ERR_UNSUPPORTED;
+    }
+    if (M == 0) return DODT_OK;
+    return launch_fc_skinny((ctx ? ctx : f->ctx)->stream, a, so, true, true);
 }
 
 double dodt_fc_flops(const dodt_fc* f, int M) {

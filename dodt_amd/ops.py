@@ -188,6 +188,19 @@ def mean_fusion(ctx, d_a, d_b, rows, d_n, row_floats, d_out):
                                         int(row_floats), _p(d_out)), 'dodt_mean_fusion')
 
 
+def rows_to_bf16(ctx, d_a, d_b, rows, d_n, row_floats, in_ld, d_out, out_ld):
+    """d_out (rows, out_ld) bf16 (uint16 storage) = bf16((d_a + d_b) / 2) [bf16(d_a) when d_b is None] over the first
+    row_floats elements of min(*d_n, rows) rows (input rows in_ld floats apart), zeros behind them: the first
+    layer's rows of a bf16 head (dodt_rows_to_bf16)."""
+    _lib.check(ctx.lib.dodt_rows_to_bf16(ctx.handle, _p(d_a), _p(d_b), int(rows), _p(d_n), int(row_floats),
+                                         int(in_ld), _p(d_out), int(out_ld)), 'dodt_rows_to_bf16')
+
+
+def bf16_to_float(a):
+    """uint16 array of bf16 bit patterns -> float32 (host side of tests and tools)."""
+    return (np.asarray(a, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
 class FullyConnected(object):
     """y = act(x w + b) on the device (dodt_fc_*).  w (K,N) row-major, the layout of the
     TF variable (conv kernels reshaped (kh*kw*cin, cout))."""
@@ -228,6 +241,25 @@ class FullyConnected(object):
         _lib.check(c.lib.dodt_fc_forward_split(
             self.handle, c.handle, _p(d_x), int(self.K if ldx is None else ldx), int(M), _p(d_m),
             len(widths), w, ys), 'dodt_fc_forward_split')
+
+    def bf16_row_elems(self):
+        """bf16 elements an input row of forward_bf16 must hold (zeros beyond K); 0: the layer has no such path."""
+        return int(self.ctx.lib.dodt_fc_bf16_row_elems(self.handle)) if self.dtype == 'bf16' else 0
+
+    def forward_bf16(self, d_x, M, d_y, ldx, ldy=None, d_m=None, y_bf16=True, ctx=None):
+        """The layer on rows that are already bf16 (d_x: uint16 storage, ldx elements per row); d_y bf16 rows
+        (y_bf16) or float32."""
+        c = ctx or self.ctx
+        _lib.check(c.lib.dodt_fc_forward_bf16(self.handle, c.handle, _p(d_x), int(ldx), int(M), _p(d_m), _p(d_y),
+                                              int(self.N if ldy is None else ldy), 1 if y_bf16 else 0),
+                   'dodt_fc_forward_bf16')
+
+    def forward_split_bf16(self, d_x, M, d_ys, widths, ldx, d_m=None, ctx=None):
+        c = ctx or self.ctx
+        w = (C.c_int * len(widths))(*[int(v) for v in widths])
+        ys = (C.c_void_p * len(d_ys))(*[_p(y) for y in d_ys])
+        _lib.check(c.lib.dodt_fc_forward_split_bf16(
+            self.handle, c.handle, _p(d_x), int(ldx), int(M), _p(d_m), len(widths), w, ys), 'dodt_fc_forward_split_bf16')
 
     def flops(self, M):
         return 2.0 * M * self.K * self.N

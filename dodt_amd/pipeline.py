@@ -80,14 +80,15 @@ class FramePairPipeline(object):
         # streams: conv stacks of the two nets side by side, per-frame work on its own.
         # A second pipeline in the same process takes the first one's streams
         # (`reuse_streams_of`): new ones would share hardware queues with them (see below).
-        # `tail_sets` (1 or 2; DODT_PIPE_TAIL_SETS overrides): sets of side streams.  With one set a frame's
-        # stream carries prep k, tail k-1, prep k+1, tail k, ... in a row, so a step cannot be shorter than a
-        # tail's dependent launch chain plus a prep -- what bounds the step once the convs run on the bf16 MFMA
-        # (chain 1.2 ms against 0.9 ms of convs).  With two sets the steps alternate between them by parity (set p:
-        # prep k, tail k, prep k+2, tail k+2, ...): the tails of consecutive steps overlap, every buffer a step
-        # touches is still used in stream order by its own parity's streams.
+        # `tail_sets` (1, the default, or 2; DODT_PIPE_TAIL_SETS overrides): sets of side streams.  With one set a
+        # frame's stream carries prep k, tail k-1, prep k+1, tail k, ... in a row.  With two sets the steps alternate
+        # between them by parity (set p: prep k, tail k, prep k+2, tail k+2, ...): the tails of consecutive steps
+        # may overlap, every buffer a step touches is still used in stream order by its own parity's streams.
+        # Built in round 4 for the bf16 path, whose step looked bound by a tail's dependent launch chain, and
+        # measured: SLOWER in every mode (fp32 324 -> 276 pairs/s, bf16 convs + heads 836 -> 522: six streams
+        # instead of four) -- opt-in only.
         if tail_sets is None:
-            tail_sets = 2 if conv_dtype == 'bf16' else 1
+            tail_sets = 1
         tail_sets = int(os.environ.get('DODT_PIPE_TAIL_SETS', tail_sets))
         if tail_sets not in (1, 2):
             raise ValueError('tail_sets must be 1 or 2')

@@ -347,6 +347,20 @@ int dodt_fc_forward(dodt_fc* fc, dodt_ctx* ctx, const float* d_x, const float* d
  * DODT_ERR_UNSUPPORTED. */
 int dodt_fc_forward_split(dodt_fc* fc, dodt_ctx* ctx, const float* d_x, int ldx, int M, const int32_t* d_m,
                           int parts, const int* widths, float* const* d_ys);
+/* bf16 heads with bf16 activations in HBM (round 4).  A DODT_FC_BF16 layer also takes input rows that are
+ * ALREADY bf16 (ldx in elements; dodt_fc_bf16_row_elems(fc) of them per row, zeros beyond K; 0 = no such path for
+ * this layer) and writes bf16 rows (y_bf16 != 0, ldy in elements; rounded to nearest even -- the rounding the next
+ * layer's load would apply, so the arithmetic is the one of dodt_fc_forward on DODT_FC_BF16 layers) or float32.
+ * Layers with N % 128 == 0 and K >= 128 (both operands staged by LDS-DMA), and the output layers dodt_fc_forward_split
+ * takes (float32 output).  dodt_rows_to_bf16 makes the first layer's rows: bf16((a + b) / 2) -- the heads' mean
+ * fusion, avod_fc_layer_utils.py:38-41 -- or bf16(a) when d_b is NULL, zero tail up to out_ld. */
+int dodt_fc_bf16_row_elems(const dodt_fc* fc);
+int dodt_fc_forward_bf16(dodt_fc* fc, dodt_ctx* ctx, const void* d_x_bf16, int ldx, int M, const int32_t* d_m,
+                         void* d_y, int ldy, int y_bf16);
+int dodt_fc_forward_split_bf16(dodt_fc* fc, dodt_ctx* ctx, const void* d_x_bf16, int ldx, int M, const int32_t* d_m,
+                               int parts, const int* widths, float* const* d_ys);
+int dodt_rows_to_bf16(dodt_ctx* ctx, const float* d_a, const float* d_b, int rows, const int32_t* d_n,
+                      int row_floats, int in_ld, void* d_out_bf16, int out_ld);
 double dodt_fc_flops(const dodt_fc* fc, int M);
 
 /* ---- a13: NMS -------------------------------------------------------------------------

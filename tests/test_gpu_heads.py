@@ -114,6 +114,74 @@ def test_fully_connected_bf16_matches_its_oracle(ctx, M, K, N, relu, fuse):
     fc.close()
 
 
+@pytest.mark.parametrize('M,K,N,relu,fuse', [
+    (1024, 2048, 2048, True, False),      # a hidden layer of the stage-2 / correlation heads
+    (1000, 1568, 2048, True, True),       # stage-2 fc6: mean of the two crops, K padded to 1600
+    (513, 1225, 2048, True, False),       # correlation fc6: K padded to 1280, rows 1248 floats apart
+    (64, 128, 128, False, False), (2100, 256, 256, True, False), (37, 192, 384, True, True)])
+def test_fully_connected_on_bf16_rows_matches_its_oracle(ctx, M, K, N, relu, fuse):
+    """The bf16 heads' round-4 path: dodt_rows_to_bf16 makes the layer's input rows (bf16((a + b) / 2), zero tail),
+    fc_bf16_dma_kernel reads them and the pre-swizzled bf16 weights by LDS-DMA.  Same rounding points as the
+    oracle's bf16 restatement, so with float32 output only the summation order differs (1e-4 of the scale, like
+    every FC test); with bf16 output every element is the float32 result rounded once more (half a bf16 ulp)."""
+    rng = np.random.default_rng(M + K + N + 7)
+    in_ld = K + 23 if K == 1225 else K
+    xs = rng.normal(size=(M, in_ld)).astype(np.float32)
+    x2 = rng.normal(size=(M, in_ld)).astype(np.float32) if fuse else None
+    w = rng.normal(0, np.sqrt(2.0 / K), size=(K, N)).astype(np.float32)
+    b = rng.normal(0, 0.1, size=N).astype(np.float32)
+    fc = ops.FullyConnected(ctx, w, b, relu, dtype='bf16')
+    ld16 = fc.bf16_row_elems()
+    assert ld16 == -(-K // 64) * 64
+    d_rows = ctx.array(np.full((M + 3, ld16), 0x7fc0, np.uint16))         # NaNs: the zero tail must be written
+    d_m = ctx.array(np.array([M], np.int32))
+    ops.rows_to_bf16(ctx, ctx.array(xs), None if x2 is None else ctx.array(x2), M + 3, d_m, K, in_ld, d_rows, ld16)
+    rows = ops.bf16_to_float(d_rows.download())
+    xin = oheads.mean_fusion(xs[:, :K], x2[:, :K]) if fuse else xs[:, :K]
+    assert np.array_equal(rows[:M, :K], tfops.round_bf16(xin)) and not rows[:M, K:].any()
+    assert np.isnan(rows[M:]).all()                                       # rows beyond *d_m untouched
+    want = oheads.fc(xin, w, b, relu, dtype='bf16')
+    d_y = ctx.array(np.full((M, N), np.nan, np.float32))
+    fc.forward_bf16(d_rows, M, d_y, ldx=ld16, d_m=d_m, y_bf16=False)
+    _close(d_y.download(), want)
+    d_y16 = ctx.array(np.full((M, N + 8), 0x7fc0, np.uint16))
+    fc.forward_bf16(d_rows, M, d_y16, ldx=ld16, ldy=N + 8, y_bf16=True)
+    got = ops.bf16_to_float(d_y16.download())
+    assert np.isnan(got[:, N:]).all()
+    scale = np.abs(want).max()
+    assert (np.abs(got[:, :N] - want) <= 2.0 ** -8 * np.abs(want) * 1.001 + 1e-4 * scale).all()
+    assert np.array_equal(got[:, :N], tfops.round_bf16(got[:, :N]))
+    fc.close()
+
+
+def test_output_layers_on_bf16_rows(ctx):
+    """A head's cls | offsets | angle-vector layers reading bf16 rows (dodt_fc_forward_split_bf16 / the skinny path
+    of dodt_fc_forward_bf16): the values of the float32-row form on rows that hold bf16 values."""
+    rng = np.random.default_rng(12)
+    M, K, widths = 1000, 2048, (2, 10, 2)
+    x = tfops.round_bf16(rng.normal(size=(M, K)).astype(np.float32))
+    w = rng.normal(0, np.sqrt(2.0 / K), size=(K, sum(widths))).astype(np.float32)
+    b = rng.normal(0, 0.1, size=sum(widths)).astype(np.float32)
+    fc = ops.FullyConnected(ctx, w, b, False, dtype='bf16')
+    assert fc.bf16_row_elems() == K
+    x16 = (x.view(np.uint32) >> 16).astype(np.uint16)
+    d_ys = [ctx.array(np.full((M, n), 7.0, np.float32)) for n in widths]
+    fc.forward_split_bf16(ctx.array(x16), M, d_ys, widths, ldx=K, d_m=ctx.array(np.array([900], np.int32)))
+    want, c0 = oheads.fc(x, w, b, False, dtype='bf16'), 0
+    for d_y, n in zip(d_ys, widths):
+        got = d_y.download()
+        _close(got[:900], want[:900, c0:c0 + n])
+        assert np.all(got[900:] == 7.0)
+        c0 += n
+    d_y = ctx.empty((M, sum(widths)), np.float32)
+    fc.forward_bf16(ctx.array(x16), M, d_y, ldx=K, y_bf16=False)
+    _close(d_y.download(), want)
+    fc.close()
+    with pytest.raises(Exception):
+        f32 = ops.FullyConnected(ctx, w, b, False)
+        f32.forward_bf16(ctx.array(x16), M, d_y, ldx=K, y_bf16=False)
+
+
 def test_fully_connected_strides_and_device_row_count(ctx):
     rng = np.random.default_rng(8)
     M, K, N, ldx, ldy = 200, 256, 256, 512, 300
