@@ -473,12 +473,19 @@ def main():
                 gather_block((state['sent'] // G) % 2)
                 state['sent'] += G
 
+        # the stream of frames is known ahead: every step hands the pipeline the next step's inputs as well, whose
+        # prep then goes in front of the previous step's tail (FramePairPipeline.run: lookahead; DODT_BENCH_LOOKAHEAD=0
+        # switches it off)
+        ahead = os.environ.get('DODT_BENCH_LOOKAHEAD', '1') != '0'
+
         def step(i):
-            p = batches[i % n_batches]
+            p = batches[pipe.step_idx % n_batches]
+            q = batches[(pipe.step_idx + 1) % n_batches]
             if from_host:
-                pipe.run_from_host(p['h_pts'], p['n'], p['h_imgs'], p['heads'])
+                pipe.run_from_host(p['h_pts'], p['n'], p['h_imgs'], p['heads'],
+                                   lookahead=(q['h_pts'], q['n'], q['h_imgs']) if ahead else None)
             else:
-                pipe.run(p['pts'], p['n'], p['imgs'], p['heads'])
+                pipe.run(p['pts'], p['n'], p['imgs'], p['heads'], lookahead=(q['pts'], q['n'], q['imgs']) if ahead else None)
             ship(pipe.step_idx - 1)
 
         def drain():
@@ -553,6 +560,9 @@ def main():
         # ---- the conv stacks alone (each net by itself on its own stream, so that kernel
         #      durations do not overlap), layer by layer: HIP events on the stream the kernels run on
         reps = max(3, min(steps, 10))
+        # (the stand-alone forwards read the inputs the last steps left in the pipeline's buffers)
+        pipe.bev_net.set_input(pipe.in_bev[0])
+        pipe.img_net.set_input(pipe.in_img[0])
         nets = ((pipe.bev_net, ctx, pipe.feat[0]['bev_feat'], pipe.feat[0]['bev_bneck']),
                 (pipe.img_net, pipe.img_ctx, pipe.feat[0]['img_feat'], pipe.feat[0]['img_bneck']))
         conv_ms = 0.0
@@ -622,7 +632,7 @@ def main():
             corr_map = pipe.head_scratch[0]['corr_map']
             us = timed(lambda: ops.correlation(ctx, feat_b0, feat_b1, bev_hw + (FC,), CORR_MAX_DISP,
                                                CORR_STRIDE2, CORR_PAD, corr_map))
-            hbm.append(dict(kernel='correlation_kernel', stage='f1 correlation of the pair\'s BEV features',
+            hbm.append(dict(kernel='correlation_sp_kernel', stage='f1 correlation of the pair\'s BEV features',
                             algorithmic_bytes=(2 * FC + CORR_CH) * pipe.bev_fh * pipe.bev_fw * 4, us=us))
             # NMS #1 alone on the last step's candidates (n(n-1)/2 pair tests, bytes =
             # 20 n + 8 n ceil(n/64); latency-bound, the bandwidth fraction is informative only)

@@ -106,6 +106,8 @@ SIGNATURES = {
                                       _vp, _vp, _vp]),
     'dodt_extractor_input': (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_longlong)]),
     'dodt_extractor_forward': (_i, [_vp, _pf, _pf, _pf]),
+    'dodt_extractor_forward_padded': (_i, [_vp, _pf, _pf, _pf]),
+    'dodt_extractor_set_input': (_i, [_vp, _pf]),
     'dodt_extractor_read_activation': (_i, [_vp, C.c_char_p, _vp,
                                             C.POINTER(_i), C.POINTER(_i),
                                             C.POINTER(_i)]),

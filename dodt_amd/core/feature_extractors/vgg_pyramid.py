@@ -88,6 +88,19 @@ class _VggPyr(object):
             None if d_bottleneck is None else C.c_void_p(d_bottleneck.ptr)),
             'dodt_extractor_forward')
 
+    def forward_device_padded(self, d_x0, d_feat, d_bottleneck=None):
+        """forward_device on an input the caller keeps in the extractor's input layout, (batch, PAD_TOP + h, w, c)
+        with zero pad rows: read in place, no copy (dodt_extractor_forward_padded)."""
+        _lib.check(self._ctx.lib.dodt_extractor_forward_padded(
+            self._handle, C.c_void_p(d_x0.ptr), C.c_void_p(d_feat.ptr),
+            None if d_bottleneck is None else C.c_void_p(d_bottleneck.ptr)), 'dodt_extractor_forward_padded')
+
+    def set_input(self, d_x0):
+        """Forwards without an input argument read d_x0 (extractor input layout) from now on; None: the extractor's
+        own buffer again (dodt_extractor_set_input)."""
+        _lib.check(self._ctx.lib.dodt_extractor_set_input(
+            self._handle, None if d_x0 is None else C.c_void_p(d_x0.ptr)), 'dodt_extractor_set_input')
+
     def forward_timed(self, d_in, d_feat, d_bottleneck=None):
         """One forward with a HIP event pair around every layer; waits for the stream.  Returns a
         list of dicts in launch order: name, kernel (the __global__ function), launches, items,

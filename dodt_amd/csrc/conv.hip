@@ -144,10 +144,11 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         // two rounds); if none does, the one with the most items (half-height tiles were tried for
         // the small maps: slower, the per-item cost grows faster than the balance improves)
         long best_n = 0;
+        static const long per_cu = getenv("DODT_CONV_BF16_ITEMS_PER_CU") ? atol(getenv("DODT_CONV_BF16_ITEMS_PER_CU")) : 4;
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].dma || Cout % vs[i].BN != 0) continue;
             const long n = (long)dodt::ceil_div(H, vs[i].TH) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch;
-            const bool enough = n >= 4L * num_cus, best_enough = best_n >= 4L * num_cus;
+            const bool enough = n >= per_cu * num_cus, best_enough = best_n >= per_cu * num_cus;
             if (best < 0 || (enough && !best_enough) || (enough && best_enough && vs[i].BN > vs[best].BN) ||
                 (!enough && !best_enough && n > best_n)) {
                 best = (int)i; best_n = n;
@@ -361,6 +362,7 @@ struct dodt_extractor {
     bool bneck_loaded = false;
     double flops = 0.0;
     bool timed = false;   // this forward records an event pair around every layer
+    float* own_x0 = nullptr;   // the extractor's own input buffer while dodt_extractor_set_input points X0 elsewhere
 };
 
 namespace {
@@ -763,6 +765,7 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
 int dodt_extractor_destroy(dodt_extractor* ex) {
     if (!ex) return DODT_OK;
     if (ex->ctx) (void)hipStreamSynchronize(ex->ctx->stream);
+    if (ex->own_x0) ex->buf[X0].ptr = ex->own_x0;      // (never free a caller's input buffer)
     for (int i = 0; i < NBUF; ++i)
         if (ex->buf[i].ptr) (void)hipFree(ex->buf[i].ptr);
     for (Layer& l : ex->layers) {
@@ -1061,6 +1064,25 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
                            ex->bneck_shift, d_bottleneck_out);
         DODT_LAUNCH_CHECK();
     }
+    return DODT_OK;
+}
+
+int dodt_extractor_forward_padded(dodt_extractor* ex, const float* d_x0, float* d_feat_out,
+                                  float* d_bottleneck_out) {
+    DODT_REQUIRE(ex && d_x0 && d_feat_out, "dodt_extractor_forward_padded: NULL argument");
+    // the first layer reads the caller's buffer in place of the extractor's own input buffer
+    Buffer& x0 = ex->buf[X0];
+    float* cur = x0.ptr;
+    x0.ptr = const_cast<float*>(d_x0);
+    const int rc = dodt_extractor_forward(ex, nullptr, d_feat_out, d_bottleneck_out);
+    x0.ptr = cur;
+    return rc;
+}
+
+int dodt_extractor_set_input(dodt_extractor* ex, const float* d_x0) {
+    DODT_REQUIRE(ex, "dodt_extractor_set_input: extractor is NULL");
+    if (!ex->own_x0) ex->own_x0 = ex->buf[X0].ptr;
+    ex->buf[X0].ptr = d_x0 ? const_cast<float*>(d_x0) : ex->own_x0;
     return DODT_OK;
 }
 

@@ -127,11 +127,14 @@ class FramePairPipeline(object):
         if img_c != self.feat_c:
             raise ValueError('mean fusion needs equal feature depths')
         # conv inputs, double-buffered so that step k+1 is prepared under the convs of step k
-        self.in_bev = [ctx.empty((self.nf, self.bev_h, self.bev_w, cfg['bev_depth']), np.float32)
+        # (in the extractors' own input layout -- the BEV maps behind four zero rows, bev_vgg_pyramid.py:58 --, so
+        #  that the first conv layer reads them in place: forward_device_padded)
+        self.bev_pad = self.bev_net.PAD_TOP
+        self.in_bev = [ctx.zeros((self.nf, self.bev_pad + self.bev_h, self.bev_w, cfg['bev_depth']), np.float32)
                        for _ in range(2)]
-        self.in_img = [ctx.empty((self.nf, self.img_h, self.img_w, 4), np.float32)
+        self.in_img = [ctx.zeros((self.nf, self.img_net.PAD_TOP + self.img_h, self.img_w, 4), np.float32)
                        for _ in range(2)]
-        self.d_bev_in = self._views(self.in_bev[0], (self.bev_h, self.bev_w, cfg['bev_depth']))
+        self.d_bev_in = self._views(self.in_bev[0], (self.bev_h, self.bev_w, cfg['bev_depth']), self.bev_pad)
 
         # ---- dense heads (weights shared, scratch per side stream) ------------------------
         f32, i32 = np.float32, np.int32
@@ -164,13 +167,18 @@ class FramePairPipeline(object):
             bev_bneck=ctx.empty((self.nf, self.bev_fh, self.bev_fw, 1), f32),
             img_feat=ctx.empty((self.nf, self.img_fh, self.img_fw, FC), f32),
             img_bneck=ctx.empty((self.nf, self.img_fh, self.img_fw, 1), f32)) for _ in range(2)]
+        # what a step's prep leaves for its tail, THREE deep (step k: set k % 3): with look-ahead (run(...,
+        # lookahead=)) the prep of step k + 1 is enqueued in front of the tail of step k - 1, which still reads
+        # the set of its own step
+        self.prep3 = [[dict(occ=ctx.empty((self.nz, (self.nx + 31) // 32), np.uint32),
+                            keep=ctx.empty((N,), i32), count=ctx.zeros((1,), i32),
+                            bev_norm=ctx.empty((N, 4), f32), img_norm=ctx.empty((N, 4), f32),
+                            anchors=ctx.empty((N, 6), f32)) for _ in range(self.nf)] for _ in range(3)]
+        if 3 * self.nf > 32:
+            raise ValueError('at most 10 frames per step (count fetch slots)')
         self.fr2 = [[], []]
         for f in range(2 * self.nf):
             b = dict(
-                occ=ctx.empty((self.nz, (self.nx + 31) // 32), np.uint32),
-                keep=ctx.empty((N,), i32), count=ctx.zeros((1,), i32),
-                bev_norm=ctx.empty((N, 4), f32), img_norm=ctx.empty((N, 4), f32),
-                anchors=ctx.empty((N, 6), f32),
                 rpn_bev_roi=ctx.empty((N, 3, 3, 1), f32), rpn_img_roi=ctx.empty((N, 3, 3, 1), f32),
                 regressed=ctx.empty((N, 6), f32), prop_bev=ctx.empty((N, 4), f32),
                 scores=ctx.empty((N,), f32),
@@ -193,7 +201,8 @@ class FramePairPipeline(object):
                     b.update(corr_rois=ctx.zeros((P, self.corr_head.in_ld), f32),
                              corr_offsets=ctx.empty((P, 3), f32))
             self.fr2[f // self.nf].append(b)
-        self.fr = self.fr2[0]          # buffers of the most recently finished step
+        self.fr = [dict(b, **p) for b, p in zip(self.fr2[0], self.prep3[0])]   # buffers of the most recently finished step
+        self.prepped = -1              # step whose prep a look-ahead has already enqueued
         self.step_idx = 0
         self.pending = None            # step whose tail has not been enqueued yet
         # detection records of a step: what the all-gather ships.  A ring of R >= 2
@@ -244,9 +253,11 @@ class FramePairPipeline(object):
         """(tail streams, prep streams) of the steps with parity `cur`."""
         return self.stream_sets[cur % len(self.stream_sets)]
 
-    def _views(self, arr, shape):
-        n = int(np.prod(shape)) * 4
-        return [arr.offset(n * f, shape) for f in range(self.nf)]
+    def _views(self, arr, shape, pad_top=0):
+        """Per-frame views of a batch buffer whose frames are pad_top + shape[0] rows tall: the rows behind the pad."""
+        row = int(np.prod(shape[1:])) * 4
+        frame = (pad_top + shape[0]) * row
+        return [arr.offset(frame * f + pad_top * row, shape) for f in range(self.nf)]
 
     def use_record_buffers(self, rec_ptrs, cnt_ptrs):
         """Write detection records into caller-owned device memory (e.g. buffers registered with
@@ -270,14 +281,9 @@ class FramePairPipeline(object):
                                 [d_cnt_ring.ptr + nc * i for i in range(R)])
 
     # ------------------------------------------------------------------------------------
-    def run_from_host(self, h_points, n_points, h_images, heads=None, ego_motion=None):
-        """run() for raw frames still in (page-locked) host memory: lists of PinnedArray --
-        points (n_max,4) float32 of which n_points[f] rows are valid, images (H,W,3) uint8.
-        The copies are enqueued on each frame's prep stream in front of its prep kernels, so
-        they travel under the kernels of the previous step; the host does not wait for them
-        (the caller keeps the pinned buffers untouched until that step's prep has run, e.g.
-        by alternating two sets)."""
-        cur = self.step_idx & 1
+    def _stage_from_host(self, k, h_points, n_points, h_images):
+        """Enqueue the copies of step k's raw frames from pinned host memory on its prep streams."""
+        cur = k & 1
         _, preps = self._streams(cur)
         ns = len(preps)
         if not hasattr(self, 'stage'):
@@ -295,9 +301,66 @@ class FramePairPipeline(object):
             di.upload_async(h_images[f], ctx=c)
             d_pts.append(dp)
             d_imgs.append(di)
-        return self.run(d_pts, n_points, d_imgs, heads, ego_motion)
+        return d_pts, d_imgs
 
-    def run(self, d_points, n_points, d_images, heads=None, ego_motion=None):
+    def run_from_host(self, h_points, n_points, h_images, heads=None, ego_motion=None, lookahead=None):
+        """run() for raw frames still in (page-locked) host memory: lists of PinnedArray --
+        points (n_max,4) float32 of which n_points[f] rows are valid, images (H,W,3) uint8.
+        The copies are enqueued on each frame's prep stream in front of its prep kernels, so
+        they travel under the kernels of the previous step; the host does not wait for them
+        (the caller keeps the pinned buffers untouched until that step's prep has run, e.g.
+        by alternating two sets)."""
+        if self.prepped == self.step_idx:       # staged and prepared by the previous call's look-ahead
+            d_pts = d_imgs = None
+        else:
+            d_pts, d_imgs = self._stage_from_host(self.step_idx, h_points, n_points, h_images)
+        if lookahead is not None:
+            # (the copies of step k + 1 go behind what its prep streams hold now, i.e. behind step k's prep)
+            la = tuple(lookahead) + (None,) * (4 - len(lookahead))
+            nd_pts, nd_imgs = self._stage_from_host(self.step_idx + 1, la[0], la[1], la[2])
+            lookahead = (nd_pts, la[1], nd_imgs, la[3])
+        return self.run(d_pts, n_points, d_imgs, heads, ego_motion, lookahead)
+
+    PREP_DONE_MARK = 244        # mark slots 244..246 of the prep contexts: end of a step's prep, by step % 3
+
+    def _prep(self, k, d_points, n_points, d_images, ego_motion, ahead):
+        """a0-a7 of step k: the data side of the reference's create_feed_dict, one frame per prep stream; its end
+        is marked on those streams (PREP_DONE_MARK + k % 3).  `ahead`: enqueued by the previous step's run()
+        (look-ahead): the conv inputs of this parity were last read by the convs of step k - 2, which the prep
+        streams are told to wait for (with the usual order, behind the tail of step k - 2, that is implied)."""
+        nf = self.nf
+        mean = (self.img_net._R_MEAN, self.img_net._G_MEAN, self.img_net._B_MEAN)
+        cur = k & 1
+        sides, preps = self._streams(cur)
+        ns = len(sides)
+        bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w, self.cfg['bev_depth']), self.bev_pad)
+        img_in = self._views(self.in_img[cur], (self.img_h, self.img_w, 4), self.img_net.PAD_TOP)
+        if ahead and k >= 2:
+            for c in set(preps):
+                c.wait_mark(self.ctx, self.CONV_DONE_MARK + cur)
+                c.wait_mark(self.img_ctx, self.CONV_DONE_MARK + cur)
+        for f in range(nf):
+            c, b = preps[f % ns], self.prep3[k % 3][f]
+            self._mark(c, k, 'prep%d_start' % f)
+            bp = self.bp
+            if ego_motion is not None and self.fps == 2 and f % 2 == 1 \
+                    and ego_motion[f // 2] is not None:
+                bp = ops.with_ego_motion(self.bp, *ego_motion[f // 2])
+            ops.bev_slices(c, d_points[f], n_points[f], bp, bev_in[f], b['occ'])
+            ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
+                              b['keep'], b['count'])
+            ops.fetch_i32_begin(c, b['count'], 1, 3 * f + k % 3)
+            ops.project_anchors_f64(c, self.d_anchor_table, b['keep'], self.n_all, b['count'],
+                                    self.bev_extents_flat, self.p2, self.image_wh,
+                                    b['bev_norm'], b['img_norm'], b['anchors'])
+            ops.img_preprocess(c, d_images[f], (self.image_wh[1], self.image_wh[0]),
+                               (self.img_h, self.img_w), 4, mean, img_in[f])
+            self._mark(c, k, 'prep%d_end' % f)
+        for c in set(preps):
+            c.mark(self.PREP_DONE_MARK + k % 3)
+        self.prepped = k
+
+    def run(self, d_points, n_points, d_images, heads=None, ego_motion=None, lookahead=None):
         """Enqueue one step.  Lists of length 2 * pairs_per_step, frame order
         [pair0 f0, pair0 f1, pair1 f0, ...]: d_points[f] (n,4) float32 velodyne xyzi;
         d_images[f] (H,W,3) uint8; heads[f] dict of device arrays rpn_logits (N,2),
@@ -308,6 +371,10 @@ class FramePairPipeline(object):
         registration of the pair's second frame into the first frame's coordinates
         (datasets.kitti.kitti_tracking_utils.coordinate_transform; applied to the second
         frame's BEV maps, not to its anchor-filter grid, like the reference).
+        lookahead: None, or (d_points, n_points, d_images[, ego_motion]) of the NEXT step: its prep is enqueued now,
+        in front of the previous step's tail on the side streams, so that the next step's convs do not wait for
+        that tail (a caller that knows its next inputs -- a stream of frames -- should pass them; the next call
+        must then be made with those inputs).
         Returns the parity (0/1) of the record buffers this step will fill.  The
         detections of the PREVIOUS step are complete on the main stream when this returns
         (self.d_records / self.fr / self.last_anchor_counts then describe that step);
@@ -315,44 +382,27 @@ class FramePairPipeline(object):
         main, nf = self.ctx, self.nf
         if (heads is None) != (self.rpn_head is not None):
             raise ValueError('pass `heads` exactly when the pipeline has no head_params')
-        mean = (self.img_net._R_MEAN, self.img_net._G_MEAN, self.img_net._B_MEAN)
         cur = self.step_idx & 1
         sides, preps = self._streams(cur)
         ns = len(sides)
         fr, feat = self.fr2[cur], self.feat[cur]
-        bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w, self.cfg['bev_depth']))
-        img_in = self._views(self.in_img[cur], (self.img_h, self.img_w, 4))
-        # -- a0-a7: data side of the reference's create_feed_dict, one frame per prep stream.
-        #    These buffers were last read by the tail of step k-2 (same parity): the prep
-        #    streams were told to wait for it when it was enqueued (below).
         k = self.step_idx
-        for f in range(nf):
-            c, b = preps[f % ns], fr[f]
-            self._mark(c, k, 'prep%d_start' % f)
-            bp = self.bp
-            if ego_motion is not None and self.fps == 2 and f % 2 == 1 \
-                    and ego_motion[f // 2] is not None:
-                bp = ops.with_ego_motion(self.bp, *ego_motion[f // 2])
-            ops.bev_slices(c, d_points[f], n_points[f], bp, bev_in[f], b['occ'])
-            ops.anchor_filter(c, b['occ'], self.nx, self.nz, self.d_cells, self.n_all,
-                              b['keep'], b['count'])
-            ops.fetch_i32_begin(c, b['count'], 1, 2 * f + cur)
-            ops.project_anchors_f64(c, self.d_anchor_table, b['keep'], self.n_all, b['count'],
-                                    self.bev_extents_flat, self.p2, self.image_wh,
-                                    b['bev_norm'], b['img_norm'], b['anchors'])
-            ops.img_preprocess(c, d_images[f], (self.image_wh[1], self.image_wh[0]),
-                               (self.img_h, self.img_w), 4, mean, img_in[f])
-            self._mark(c, k, 'prep%d_end' % f)
-        for c in preps:
-            main.wait_for(c)
-            self.img_ctx.wait_for(c)
+        if self.prepped != k:      # (else: enqueued by the previous call's look-ahead)
+            self._prep(k, d_points, n_points, d_images, ego_motion, ahead=False)
+        for c in set(preps):
+            main.wait_mark(c, self.PREP_DONE_MARK + k % 3)
+            self.img_ctx.wait_mark(c, self.PREP_DONE_MARK + k % 3)
         # -- a8-a10: conv stacks, all frames per launch, the two nets side by side --------
         self._mark(main, k, 'bev_start')
         self._mark(self.img_ctx, k, 'img_start')
-        self.bev_net.forward_device(self.in_bev[cur], feat['bev_feat'], feat['bev_bneck'])
-        self.img_net.forward_device(self.in_img[cur], feat['img_feat'], feat['img_bneck'])
+        self.bev_net.forward_device_padded(self.in_bev[cur], feat['bev_feat'], feat['bev_bneck'])
+        self.img_net.forward_device_padded(self.in_img[cur], feat['img_feat'], feat['img_bneck'])
         self._mark(main, k, 'bev_end')
         self._mark(self.img_ctx, k, 'img_end')
+        # -- the next step's prep, when the caller has given its inputs: in front of the previous step's tail ----
+        if lookahead is not None:
+            la = tuple(lookahead) + (None,) * (4 - len(lookahead))
+            self._prep(k + 1, la[0], la[1], la[2], la[3], ahead=True)
         # -- the previous step's tail runs under this step's convs --------------------------
         if self.pending is not None:
             self._wait_convs(self.pending)
@@ -366,10 +416,9 @@ class FramePairPipeline(object):
         # for when the tail is enqueued -- behind the NEXT step's prep on the same side stream, which therefore
         # runs under these convs instead of behind them (DODT_PIPE_EARLY_PREP=0: the wait goes in here, in front
         # of that prep, as before round 3)
-        if self.early_prep:
-            main.mark(self.CONV_DONE_MARK + cur)
-            self.img_ctx.mark(self.CONV_DONE_MARK + cur)
-        else:
+        main.mark(self.CONV_DONE_MARK + cur)
+        self.img_ctx.mark(self.CONV_DONE_MARK + cur)
+        if not self.early_prep:
             for s in sides:
                 s.wait_for(main)
                 s.wait_for(self.img_ctx)
@@ -406,13 +455,14 @@ class FramePairPipeline(object):
         fr, feat = self.fr2[cur], self.feat[cur]
         heads = st['heads']
         # kept-anchor counts of that step: fetched by its prep streams, long complete
-        counts = [ops.fetch_i32_end(preps[f % ns], 2 * f + cur, 1)[0]
+        k3 = st['step'] % 3
+        counts = [ops.fetch_i32_end(preps[f % ns], 3 * f + k3, 1)[0]
                   for f in range(nf)]
         self.last_anchor_counts = counts
+        fr = [dict(b, **p) for b, p in zip(fr, self.prep3[k3])]      # the tail's buffers + what its prep left
         self.fr = fr
         self.d_records, self.d_rec_counts = self.rec2[st['rslot']], self.cnt2[st['rslot']]
-        self.d_bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w,
-                                                       self.cfg['bev_depth']))
+        self.d_bev_in = self._views(self.in_bev[cur], (self.bev_h, self.bev_w, self.cfg['bev_depth']), self.bev_pad)
         bev_px = self.bev_fh * self.bev_fw
         img_px = self.img_fh * self.img_fw
         FC = self.feat_c

@@ -248,6 +248,15 @@ int dodt_extractor_input(dodt_extractor* ex, float** d_ptr, long long* frame_str
  * dodt_extractor_output_shape. */
 int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_out,
                            float* d_bottleneck_out);
+/* The same forward on an input the caller keeps in the extractor's own input layout: (batch, pad_top + in_h, in_w,
+ * in_c) float32 whose first pad_top rows of every frame are zero (bev_vgg_pyramid.py:58 pads the BEV map by four rows)
+ * -- read in place by the first layer, no copy into the extractor's buffer (a pipeline that double-buffers its
+ * inputs writes them straight into two such buffers). */
+int dodt_extractor_forward_padded(dodt_extractor* ex, const float* d_x0, float* d_feat_out,
+                                  float* d_bottleneck_out);
+/* Until further notice (d_x0 = NULL: back to its own buffer) forwards without an input argument read d_x0, laid out
+ * as above, as the extractor's input buffer; d_x0 must outlive that use (tools: stand-alone timing on a pipeline's inputs). */
+int dodt_extractor_set_input(dodt_extractor* ex, const float* d_x0);
 /* Size of the feature map forward() returns: (in_h, in_w, 32) for the pyramid,
  * (in_h / 8 * 4, in_w / 8 * 4, 256) for DODT_EXTRACTOR_VGG. */
 int dodt_extractor_output_shape(const dodt_extractor* ex, int* h, int* w, int* c);

@@ -136,6 +136,38 @@ def test_pipelined_steps_match_unpipelined(setup):
     assert np.array_equal(pipe.d_records.download(), rb)
 
 
+def test_lookahead_prep_gives_the_same_detections(setup):
+    """run(..., lookahead=next inputs): the next step's prep is enqueued in front of the previous step's tail (its
+    outputs are three deep).  Same detections as step-by-step runs, for every step of a short stream, also when
+    the stream ends with a prepared step that never runs and when plain calls follow."""
+    ctx, pipe = setup
+    stream = [(14, (0, 2)), (15, (1, 3)), (16, (0, 2)), (17, (2, 4)), (18, (1, 3))]
+    want, inputs = [], []
+    for seq, frames in stream:
+        pts, imgs, heads, _ = _run(ctx, pipe, seq=seq, frames=frames)
+        want.append((pipe.d_records.download().copy(), pipe.d_rec_counts.download().copy()))
+        inputs.append(([ctx.array(p) for p in pts], [len(p) for p in pts], [ctx.array(i) for i in imgs],
+                       [{k: ctx.array(v) for k, v in h.items()} for h in heads]))
+    for i, inp in enumerate(inputs):
+        nxt = inputs[i + 1][:3] if i + 1 < len(inputs) else inputs[0][:3]     # (the last look-ahead is never used)
+        pipe.run(*inp, lookahead=nxt)
+        if i > 0:
+            ctx.sync()
+            assert np.array_equal(pipe.d_records.download(), want[i - 1][0]), i
+            assert np.array_equal(pipe.d_rec_counts.download(), want[i - 1][1]), i
+    pipe.finish()
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), want[-1][0])
+    # a plain call after a look-ahead that was not followed up: the prepared step IS the next step, so the
+    # caller must pass the announced inputs -- here inputs[0] -- and gets that step's detections
+    pipe.run(*inputs[0])
+    pipe.finish()
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), want[0][0])
+    _run(ctx, pipe, seq=15, frames=(1, 3))          # and plain steps afterwards are plain steps
+    assert np.array_equal(pipe.d_records.download(), want[1][0])
+
+
 def test_pair_is_repeatable_and_independent(setup):
     """Running another pair in between does not change the result (no state leaks
     between pairs: frame-pairs shard freely across GPUs)."""

@@ -24,9 +24,10 @@ heads = None if computed else [{k: ctx.array(v) for k, v in
                                for f in frames]
 n = [120000, 120000]
 T = 8
-pipe.mark_steps = (T, T + 1) if '--two' in sys.argv else (T,)
+pipe.mark_steps = (T - 1, T, T + 1) if '--two' in sys.argv else (T,)
+ahead = '--lookahead' in sys.argv
 for i in range(T + 4):
-    pipe.run(pts, n, imgs, heads)
+    pipe.run(pts, n, imgs, heads, lookahead=(pts, n, imgs) if ahead else None)
 pipe.finish()
 ctx.sync()
 ref = pipe.marks['%d:bev_start' % T]
