@@ -669,10 +669,11 @@ def main():
     if not args.no_alt and world == 1:      # (N > 1 runs measure the sharded path only)
         # other arithmetics / batchings of the same workload, shorter runs: reported beside the
         # main measurement, never part of `value`
-        k = max(5, args.steps // 2)
+        # (at least 60 steps behind 10 warm-up steps each: round 3's alt runs were 10 steps behind 2 and read 8 % low)
+        k = max(60, args.steps)
 
         def short(conv_dtype, head_dtype, **kw):
-            a = measure(conv_dtype, k, 2, head_dtype, **kw)
+            a = measure(conv_dtype, k, 10, head_dtype, **kw)
             return {'conv_dtype': conv_dtype, 'head_dtype': head_dtype,
                     'pairs_per_step': a['pps'],
                     'value': round(world * k * a['pps'] / a['elapsed'], 3), 'unit': 'frame-pairs/s',
@@ -708,7 +709,7 @@ def main():
             if computed:
                 # BASELINE.json configs[4]: tau = 3, ~300k points per frame, 4096 proposals, heads computed
                 # (S + T), with its own HBM-side kernels alone
-                a = measure(args.conv_dtype, k, 2, args.head_dtype, points=300000, proposals=4096, tau=3,
+                a = measure(args.conv_dtype, k, 10, args.head_dtype, points=300000, proposals=4096, tau=3,
                             n_boxes=40, hbm_detail=True)
                 dj = _profile_json('dense_hbm_traffic.json')
                 for h in a.get('hbm', []):
@@ -723,7 +724,7 @@ def main():
                     'traffic_head': dj.get('head') if dj else None,
                     'traffic_source': dj.get('source') if dj else None}
             # BASELINE.json configs[1]: tau = 1 Siamese (S) path, heads' outputs injected from HBM
-            a = measure(args.conv_dtype, k, 2, 'f32', tau=1, computed=False)
+            a = measure(args.conv_dtype, k, 10, 'f32', tau=1, computed=False)
             alt['s_path'] = {'config': 'BASELINE.json configs[1]: DODT tau = 1 Siamese (S), batch = 1 frame pair, '
                                        '%s; correlation branch and dense heads NOT run, their outputs injected' % args.conv_dtype,
                              'value': round(k / a['elapsed'], 3), 'unit': 'frame-pairs/s', 'steps': k,

@@ -105,7 +105,7 @@ if trace:
                 lines.append('| %s | %d | %.2f (%d launches) | %.2f |' % (k['kernel'], k['launches_per_step'], avg, len(sel),
                                                                       k['avg_launch_us']))
         for h in bench['roofline'].get('hbm', []):
-            names = [n for n in HBM if n in h['kernel']]
+            names = [n for n in HBM if n in h['kernel']] or ([n for n in HBM if n.startswith('nms_')] if h['kernel'] == 'nms_*' else [])
             tot = 0.0
             for n in names:
                 sel = [r for r in tr if HBM[n] in r['Kernel_Name']][-20:]
@@ -200,7 +200,7 @@ if trace and bench and bench['roofline'].get('hbm') and per:
         if pl and json.loads(pl[-1])['roofline'].get('hbm'):
             hbm_rows = json.loads(pl[-1])['roofline']['hbm']
     for h in hbm_rows:
-        names = [n for n in HBM if n in h['kernel']]
+        names = [n for n in HBM if n in h['kernel']] or ([n for n in HBM if n.startswith('nms_')] if h['kernel'] == 'nms_*' else [])
         tot = f_mb = w_mb = 0.0
         for n in names:
             sel = [r for r in tr if HBM[n] in r['Kernel_Name']][-20:]
