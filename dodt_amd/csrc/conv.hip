@@ -425,9 +425,12 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.zeros = ex->d_zeros;
     // persistent workgroups: as many as stay resident, each walks items with that stride
     int grid_x = a.n_items;
-    if (!v.small_cin) {
+    {
         static const int bpc_env = getenv("DODT_CONV_BPC") ? atoi(getenv("DODT_CONV_BPC")) : 0;
-        const int bpc = (bpc_env > 0 && bpc_env < v.blocks_per_cu) ? bpc_env : v.blocks_per_cu;
+        // (the first-layer kernel is persistent since round 4: three workgroups per CU by its registers)
+        static const int small_bpc = getenv("DODT_CONV_SMALL_BPC") ? atoi(getenv("DODT_CONV_SMALL_BPC")) : 3;
+        const int vb = v.small_cin ? small_bpc : v.blocks_per_cu;
+        const int bpc = (bpc_env > 0 && bpc_env < vb) ? bpc_env : vb;
         const int resident = ex->ctx->num_cus * bpc;
         if (grid_x > resident) grid_x = resident;
     }

@@ -783,7 +783,7 @@ struct SmallCfg {
     static constexpr int BN = 32;
     static constexpr int kPatchFloats = CK * PS;
     static constexpr int kWFloats = 9 * CK * BN;
-    static constexpr int kLdsBytes = (kPatchFloats + kWFloats) * 4;
+    static constexpr int kLdsBytes = (2 * kPatchFloats + kWFloats) * 4;      // two patch images (round 4)
     static_assert(CK % 2 == 0 && MTB % 4 == 0, "shape");
 };
 
@@ -797,40 +797,28 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
     constexpr int BN = 32;
     constexpr int VEC = (CK % 4 == 0) ? 4 : 2;
 
+    // Round 4: persistent workgroups (grid = what stays resident, items taken with the grid's stride) with the weights
+    // staged once and TWO patch images: while the MFMAs of item i run, the loads of item i + 1 are in flight into
+    // registers; one barrier per item.  (Round 1-3: one item per workgroup -- fill, 108 MFMAs, stores in sequence,
+    // three workgroups per CU: 0.29-0.34 of the matrix pipe.)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sP = smem;
-    float* sW = smem + Cfg::kPatchFloats;
+    float* sW = smem + 2 * Cfg::kPatchFloats;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wm = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    int bid = blockIdx.x;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int frame = bid / tiles;
-    bid -= frame * tiles;
-    const int ty0 = (bid / a.tiles_x) * TH, tx0 = (bid % a.tiles_x) * TW;
-    const float* in = a.in + (size_t)frame * a.in_frame_stride;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int k = 0; k < MT; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-    {
-        // patch + weights -> LDS.  Every load of the thread is issued before the first LDS write (the loop with a
-        // load and its write per trip ran one global-memory latency per trip: 7 trips for the 18 x 34 x 6 patch,
-        // two thirds of the workgroup's life)
-        constexpr int CG = CK / VEC;
-        constexpr int ITEMS = PH * PW * CG;
-        constexpr int NIT = (ITEMS + 255) / 256;
-        constexpr int NW = (Cfg::kWFloats / 4 + 255) / 256;
-        float v[NIT][VEC];
-        float4 wv[NW];
-        const float4* wsrc = reinterpret_cast<const float4*>(a.w);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int t = tid + 256 * i;
-            wv[i] = t < Cfg::kWFloats / 4 ? wsrc[t] : float4{0.f, 0.f, 0.f, 0.f};
-        }
+    const int n_items = a.n_items;
+    constexpr int CG = CK / VEC;
+    constexpr int ITEMS = PH * PW * CG;
+    constexpr int NIT = (ITEMS + 255) / 256;
+    constexpr int NW = (Cfg::kWFloats / 4 + 255) / 256;
+    float v[NIT][VEC];
+    // every load of the thread is issued before the first LDS write (a loop with a load and its write per trip ran
+    // one global-memory latency per trip)
+    auto load_patch = [&](int bid) {
+        const int frame = bid / tiles, t2 = bid - frame * tiles;
+        const int ty0 = (t2 / a.tiles_x) * TH, tx0 = (t2 % a.tiles_x) * TW;
+        const float* in = a.in + (size_t)frame * a.in_frame_stride;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int t = tid + 256 * i;
@@ -850,11 +838,30 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
                 }
             }
         }
+    };
+    int bid = blockIdx.x;
+    if (bid >= n_items) return;
+    {
+        float4 wv[NW];
+        const float4* wsrc = reinterpret_cast<const float4*>(a.w);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int t = tid + 256 * i;
+            wv[i] = t < Cfg::kWFloats / 4 ? wsrc[t] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        load_patch(bid);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int t = tid + 256 * i;
             if (t < Cfg::kWFloats / 4) reinterpret_cast<float4*>(sW)[t] = wv[i];
         }
+    }
+    const int x_base = lh * PS + (li / TW) * PW + (li % TW) + wm * MT * Cfg::kRowsPerMT * PW;
+    const int w_base = lh * BN + li;
+    const long long plane = (long long)a.H * a.W * 8;
+    int buf = 0;
+    for (; bid < n_items; bid += gridDim.x) {
+        float* sP = smem + buf * Cfg::kPatchFloats;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int t = tid + 256 * i;
@@ -864,31 +871,37 @@ conv3x3_small_cin_kernel(const ConvArgs a) {
                 for (int k = 0; k < VEC; ++k) sP[(cg * VEC + k) * PS + p] = v[i][k];
             }
         }
-    }
-    __syncthreads();
-    const int x_base = lh * PS + (li / TW) * PW + (li % TW) + wm * MT * Cfg::kRowsPerMT * PW;
-    const int w_base = lh * BN + li;
+        __syncthreads();     // this item's patch (and, the first time, the weights) complete; the other image is free
+        if (bid + (int)gridDim.x < n_items) load_patch(bid + gridDim.x);     // in flight under the MFMAs
+        f32x16 acc[MT];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
+        for (int k = 0; k < MT; ++k)
 #pragma unroll
-        for (int cp = 0; cp < CK / 2; ++cp) {
-            const float wv = sW[w_base + (tap * CK + 2 * cp) * BN];
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float xv = sP[x_base + 2 * cp * PS + (mt * Cfg::kRowsPerMT + ky) * PW + kx];
-                acc[mt] = mfma32(wv, xv, acc[mt]);
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int cp = 0; cp < CK / 2; ++cp) {
+                const float wv = sW[w_base + (tap * CK + 2 * cp) * BN];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float xv = sP[x_base + 2 * cp * PS + (mt * Cfg::kRowsPerMT + ky) * PW + kx];
+                    acc[mt] = mfma32(wv, xv, acc[mt]);
+                }
             }
         }
-    }
-    float* out = a.out + (size_t)frame * a.out_frame_stride;
-    const long long plane = (long long)a.H * a.W * 8;
+        const int frame = bid / tiles, t2 = bid - frame * tiles;
+        const int ty0 = (t2 / a.tiles_x) * TH, tx0 = (t2 % a.tiles_x) * TW;
+        float* out = a.out + (size_t)frame * a.out_frame_stride;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
-        const int x = tx0 + li % TW;
-        store_tile<false, OUT16, OUT16, SPLIT>(a, out, acc[mt], 0, lh, y, x, a.W, plane,
-                                        y < a.H && x < a.W);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = ty0 + (wm * MT + mt) * Cfg::kRowsPerMT + li / TW;
+            const int x = tx0 + li % TW;
+            store_tile<false, OUT16, OUT16, SPLIT>(a, out, acc[mt], 0, lh, y, x, a.W, plane,
+                                            y < a.H && x < a.W);
+        }
+        buf ^= 1;
     }
 }
 
