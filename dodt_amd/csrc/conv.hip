@@ -94,6 +94,12 @@ extern "C" int dodt_conv_mode(void) {
 
 namespace {
 
+// bf16 LDS-DMA conv kernel: one work queue per group of blocks that share an XCD (DODT_CONV_BF16_XCD=0: one queue)
+bool bf16_xcd_queue() {
+    static const bool on = !(getenv("DODT_CONV_BF16_XCD") && atoi(getenv("DODT_CONV_BF16_XCD")) == 0);
+    return on;
+}
+
 // smallest padded pixel count wins; ties go to the larger output tile
 int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int parts, int batch,
                  int num_cus) {
@@ -410,6 +416,9 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     }
     a.counter = ex->d_counters + 2 * (&l - ex->layers.data()) + which;
     a.counter_base = ex->d_counters + 64;
+    // (eight counters, 64 bytes apart, per layer: words 2048.. of the block)
+    a.xcd_counters = ((v.dma || (v.deconv_dma && v.bf16)) && bf16_xcd_queue())
+                         ? ex->d_counters + 2048 + 128 * (&l - ex->layers.data()) : nullptr;
     a.items = ln.d_items;
     a.n_items = ln.n_items;
     a.in_part_stride = (long long)src.frame_floats() * ex->batch;
@@ -559,10 +568,18 @@ void plan_layer(Layer& l, int batch, int num_cus, bool allow_tail, std::vector<i
     const int tx = dodt::ceil_div(l.W, v.TW), ty = dodt::ceil_div(l.H, v.TH), nt = l.Cout / v.BN;
     main_items.clear();
     tail_items.clear();
-    for (int f = 0; f < batch; ++f)
-        for (int n = 0; n < nt; ++n)
+    if ((v.dma || (v.deconv_dma && v.bf16)) && bf16_xcd_queue()) {
+        // XCD-grouped queue (conv_bf16_dma.h): the channel tiles of a pixel tile next to each other
+        for (int f = 0; f < batch; ++f)
             for (int y = 0; y < ty; ++y)
-                for (int x = 0; x < tx; ++x) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
+                for (int x = 0; x < tx; ++x)
+                    for (int n = 0; n < nt; ++n) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
+    } else {
+        for (int f = 0; f < batch; ++f)
+            for (int n = 0; n < nt; ++n)
+                for (int y = 0; y < ty; ++y)
+                    for (int x = 0; x < tx; ++x) main_items.push_back(make_int4(f, n, y * v.TH, x * v.TW));
+    }
     l.main.variant = l.variant;
     l.tail.variant = -1;
     if (v.small_cin || v.wino || v.dma || v.deconv_dma) return;
@@ -1011,7 +1028,9 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
                            (long long)x0.frame_floats() / 4, ex->batch);
         DODT_LAUNCH_CHECK();
     }
-    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 64 * sizeof(int), s));   // diag words stay
+    // (the whole block: the launches' counters in words 0..63, the XCD-grouped queues' in words 2048..; the
+    //  diagnostic words in between are only read right behind the launch that wrote them)
+    DODT_HIP_CHECK(hipMemsetAsync(ex->d_counters, 0, 4096 * sizeof(int), s));
     int rc;
     auto L = [&](const char* n) -> const Layer& { return ex->layers[find_layer(ex, n)]; };
 #define RUN(name)                                           \

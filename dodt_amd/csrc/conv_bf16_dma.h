@@ -99,12 +99,25 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
     // Work items known to this workgroup: k0 is being computed, k1 follows it and k2 follows k1
     // (k2 is claimed from the atomic counter during the first step of every item, in time for
     // the copy cursor, which runs S - 1 <= 3 chunks = at most two items ahead of the MFMAs).
-    int k0 = blockIdx.x, k1 = a.n_items, k2 = a.n_items;
-    if (k0 >= a.n_items) return;
+    // The queue: one counter for the launch, or (a.xcd_counters) one per group of blocks that share an XCD, each
+    // group walking its own contiguous eighth [q_lo, q_hi) of the table.  Ticket t of a queue is item q_first + t;
+    // tickets beyond the range mean "nothing left" (a.n_items).
+    const bool grouped = a.xcd_counters != nullptr;
+    const int vx = grouped ? (int)(blockIdx.x & 7) : 0;
+    // (eighths that differ by at most one item, the larger ones first -- like the groups' block counts, so that a
+    //  launch with one item per block stays one round in every group)
+    const int q_lo = grouped ? vx * (a.n_items / 8) + min(vx, a.n_items % 8) : 0;
+    const int q_hi = grouped ? q_lo + a.n_items / 8 + (vx < a.n_items % 8 ? 1 : 0) : a.n_items;
+    const int q_blocks = grouped ? ((int)gridDim.x - vx + 7) / 8 : (int)gridDim.x;    // blocks drawing from this queue
+    const int q_first = q_lo + q_blocks;                                              // item of ticket 0
+    int* const q_counter = grouped ? a.xcd_counters + 16 * vx : a.counter;
+    auto ticket_item = [&](int t) { return q_first + t < q_hi ? q_first + t : a.n_items; };
+    int k0 = q_lo + (grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x), k1 = a.n_items, k2 = a.n_items;
+    if (k0 >= q_hi) return;
     // the successor's ticket is drawn now and read behind the prologue's copies (one barrier, and
     // the atomic's round trip hides behind the first fills)
     int pend = 0;
-    if (tid == 0) pend = atomicAdd(a.counter, 1);
+    if (tid == 0) pend = atomicAdd(q_counter, 1);
     // (a.debug & 128, tools/: start | first step | end on the chip-wide 100 MHz clock and the item
     //  count of every workgroup, 4 words each from counter_base[256])
     const bool wgstamp = (a.debug & 128) && tid == 0;
@@ -171,7 +184,7 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         copies(b);
         advance();
     }
-    if (tid == 0) s_ctrl[1] = (int)gridDim.x + pend;
+    if (tid == 0) s_ctrl[1] = ticket_item(pend);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_s_barrier();
     k1 = s_ctrl[1];           // (word 1: word 0 is rewritten by thread 0 at the top of step 0)
@@ -196,7 +209,7 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         const bool stamp = (a.debug & 32) && blockIdx.x == 1 && tid == 0 && k_stamp < 12;
         int* stamps = a.counter_base + 32 + (k_stamp < 12 ? k_stamp : 0) * 6;
         if (stamp) { stamps[0] = (int)__builtin_amdgcn_s_memtime(); stamps[1] = stamps[0]; stamps[2] = stamps[0]; }
-        if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+        if (comp_ch == 0 && tid == 0) s_ctrl[0] = ticket_item(atomicAdd(q_counter, 1));
         const float* sP = smem + PAR * Cfg::kBufFloats + row0;
         const float* sW = smem + PAR * Cfg::kBufFloats + Cfg::kPatchFloats + w_lane;
         f32x4 x[MT + 2], w[2][NT];

@@ -83,6 +83,12 @@ struct ConvArgs {
     const float* zeros;   // >= 16 bytes of zeros (Winograd kernel: source of out-of-image pixels)
     int debug;     // ablation switches for tools/ (0 in production): 1 = no epilogue
                    // stores, 2 = no global loads in the K loop, 4 = no MFMAs
+    // bf16 LDS-DMA kernel, round 4: XCD-grouped work queue.  xcd_counters != NULL: the blocks b with the same
+    // b % 8 (they share an XCD and its L2) walk the contiguous eighth b % 8 of the item table with a counter of
+    // their own (xcd_counters[16 (b % 8)], zeroed by the host) -- the table then lists the channel tiles of a pixel
+    // tile next to each other, so that a tile's input patch is fetched over the fabric once and is an L2 hit for
+    // the other channel tiles.
+    int* xcd_counters;
 };
 
 constexpr int kCK = 8;          // input channels per K chunk = one CB8 plane

@@ -134,8 +134,16 @@ deconv3x3_dma_kernel(const ConvArgs a) {
         }
     };
 
-    int comp_item = blockIdx.x;
-    if (comp_item >= a.n_items) return;
+    // the queue: one counter for the launch, or (a.xcd_counters, bf16 layers: conv_bf16_dma.h) one per group of
+    // blocks that share an XCD, each walking its own eighth [q_lo, q_hi) of the table
+    const bool grouped = a.xcd_counters != nullptr;
+    const int vx = grouped ? (int)(blockIdx.x & 7) : 0;
+    const int q_lo = grouped ? vx * (a.n_items / 8) + min(vx, a.n_items % 8) : 0;
+    const int q_hi = grouped ? q_lo + a.n_items / 8 + (vx < a.n_items % 8 ? 1 : 0) : a.n_items;
+    const int q_first = q_lo + (grouped ? ((int)gridDim.x - vx + 7) / 8 : (int)gridDim.x);      // item of ticket 0
+    int* const q_counter = grouped ? a.xcd_counters + 16 * vx : a.counter;
+    int comp_item = q_lo + (grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    if (comp_item >= q_hi) return;
     int q0 = a.n_items;
     auto advance = [&](int& it, int& ch, bool patch) {
         if (it >= a.n_items) return;
@@ -185,7 +193,10 @@ deconv3x3_dma_kernel(const ConvArgs a) {
     auto step = [&](auto par, auto first, f32x4 (&acc)[4][4][CB], int comp_ch) {
         constexpr int PAR = decltype(par)::value;
         constexpr bool FIRST = decltype(first)::value;       // the item's first chunk
-        if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+        if (comp_ch == 0 && tid == 0) {
+            const int t = q_first + atomicAdd(q_counter, 1);
+            s_ctrl[0] = t < q_hi ? t : a.n_items;
+        }
         // inputs: patch rows 4w .. 4w + 4 (input rows 4w - 1 .. 4w + 3) x column shifts 0, 1
         f32x2_t xin[5][2];
 #pragma unroll
