@@ -99,6 +99,17 @@ bool bf16_xcd_queue() {
     static const bool on = !(getenv("DODT_CONV_BF16_XCD") && atoi(getenv("DODT_CONV_BF16_XCD")) == 0);
     return on;
 }
+// the same for the fp32 Winograd F(2x2) / transposed-conv kernels (DODT_CONV_F32_XCD=0: one queue): both stacks
+// 2.90 -> 2.80 ms alone, nothing in the pipeline, half the excess fabric traffic
+bool f32_xcd_queue() {
+    static const bool on = !(getenv("DODT_CONV_F32_XCD") && atoi(getenv("DODT_CONV_F32_XCD")) == 0);
+    return on;
+}
+bool variant_xcd_queue(const dodt::KernelVariant& v) {
+    if (v.dma || (v.deconv_dma && v.bf16)) return bf16_xcd_queue();
+    if ((v.wino && v.wino_m != 4) || (v.deconv_dma && !v.bf16)) return f32_xcd_queue();
+    return false;
+}
 
 // smallest padded pixel count wins; ties go to the larger output tile
 int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int parts, int batch,
@@ -417,8 +428,7 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.counter = ex->d_counters + 2 * (&l - ex->layers.data()) + which;
     a.counter_base = ex->d_counters + 64;
     // (eight counters, 64 bytes apart, per layer: words 2048.. of the block)
-    a.xcd_counters = ((v.dma || (v.deconv_dma && v.bf16)) && bf16_xcd_queue())
-                         ? ex->d_counters + 2048 + 128 * (&l - ex->layers.data()) : nullptr;
+    a.xcd_counters = variant_xcd_queue(v) ? ex->d_counters + 2048 + 128 * (&l - ex->layers.data()) : nullptr;
     a.items = ln.d_items;
     a.n_items = ln.n_items;
     a.in_part_stride = (long long)src.frame_floats() * ex->batch;
@@ -568,7 +578,7 @@ void plan_layer(Layer& l, int batch, int num_cus, bool allow_tail, std::vector<i
     const int tx = dodt::ceil_div(l.W, v.TW), ty = dodt::ceil_div(l.H, v.TH), nt = l.Cout / v.BN;
     main_items.clear();
     tail_items.clear();
-    if ((v.dma || (v.deconv_dma && v.bf16)) && bf16_xcd_queue()) {
+    if (variant_xcd_queue(v)) {
         // XCD-grouped queue (conv_bf16_dma.h): the channel tiles of a pixel tile next to each other
         for (int f = 0; f < batch; ++f)
             for (int y = 0; y < ty; ++y)

@@ -175,8 +175,16 @@ wino3x3_f32_kernel(const ConvArgs a) {
         }
     };
 
-    int comp_item = blockIdx.x;
-    if (comp_item >= a.n_items) return;
+    // the queue: one counter for the launch, or (a.xcd_counters: see conv_bf16_dma.h) one per group of blocks that
+    // share an XCD, each walking its own eighth [q_lo, q_hi) of the table
+    const bool grouped = a.xcd_counters != nullptr;
+    const int vx = grouped ? (int)(blockIdx.x & 7) : 0;
+    const int q_lo = grouped ? vx * (a.n_items / 8) + min(vx, a.n_items % 8) : 0;
+    const int q_hi = grouped ? q_lo + a.n_items / 8 + (vx < a.n_items % 8 ? 1 : 0) : a.n_items;
+    const int q_first = q_lo + (grouped ? ((int)gridDim.x - vx + 7) / 8 : (int)gridDim.x);      // item of ticket 0
+    int* const q_counter = grouped ? a.xcd_counters + 16 * vx : a.counter;
+    int comp_item = q_lo + (grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    if (comp_item >= q_hi) return;
     int q0 = a.n_items;                          // successor of comp_item (fetched in its step 0)
     auto advance = [&](int& it, int& ch, bool patch) {
         if (it >= a.n_items) return;
@@ -271,7 +279,10 @@ wino3x3_f32_kernel(const ConvArgs a) {
     int k_stamp = 0;      // steps this wave has run (diagnostic stamps)
     auto step = [&](auto par, f32x4 (&acc)[TB][CB][16], auto& vcur, auto& vnext, int comp_ch) {
         constexpr int PAR = decltype(par)::value;
-        if (comp_ch == 0 && tid == 0) s_ctrl[0] = (int)gridDim.x + atomicAdd(a.counter, 1);
+        if (comp_ch == 0 && tid == 0) {
+            const int t = q_first + atomicAdd(q_counter, 1);
+            s_ctrl[0] = t < q_hi ? t : a.n_items;
+        }
         const float* sW = sWB + PAR * Cfg::kWFloats + w_lane;
         f32x2_t d[4][4];
         if constexpr (!Cfg::kPipe) {
