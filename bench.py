@@ -473,10 +473,12 @@ def main():
                 gather_block((state['sent'] // G) % 2)
                 state['sent'] += G
 
-        # the stream of frames is known ahead: every step hands the pipeline the next step's inputs as well, whose
-        # prep then goes in front of the previous step's tail (FramePairPipeline.run: lookahead; DODT_BENCH_LOOKAHEAD=0
-        # switches it off)
-        ahead = os.environ.get('DODT_BENCH_LOOKAHEAD', '1') != '0'
+        # the stream of frames is known ahead: a step may hand the pipeline the next step's inputs as well, whose prep
+        # then goes in front of the previous step's tail (FramePairPipeline.run: lookahead).  Measured (same box,
+        # gpurun_out/r4_exp1.txt and DESIGN.md section 8): +2.4 % with the bf16 conv path, whose convs would otherwise
+        # wait for that tail, -0.5 % with the fp32 convs, whose step is not bound there -- so it follows the conv
+        # arithmetic; DODT_BENCH_LOOKAHEAD=0 / 1 forces it
+        ahead = os.environ.get('DODT_BENCH_LOOKAHEAD', '1' if conv_dtype == 'bf16' else '0') != '0'
 
         def step(i):
             p = batches[pipe.step_idx % n_batches]
