@@ -296,6 +296,20 @@ def test_run_from_pinned_host_inputs_matches_resident_inputs(setup):
     pipe.finish()
     ctx.sync()
     assert np.array_equal(pipe.d_records.download(), want[1])
+    # the same stream with look-ahead: step k hands over step k + 1's pinned frames, which are copied and prepared
+    # in front of step k - 1's tail
+    for i in range(4):
+        pipe.run_from_host(*hosts[i % 2], lookahead=hosts[(i + 1) % 2][:3])
+        if i > 0:
+            ctx.sync()
+            assert np.array_equal(pipe.d_records.download(), want[(i - 1) % 2]), i
+    pipe.finish()
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), want[1])
+    pipe.run_from_host(*hosts[0])          # (step 4 was announced with hosts[0]; run it, so that later tests start clean)
+    pipe.finish()
+    ctx.sync()
+    assert np.array_equal(pipe.d_records.download(), want[0])
     for hp, _, hi, _ in hosts:
         for a in hp + hi:
             a.free()
