@@ -47,6 +47,7 @@ struct GemmArgs {
     float* y;
     int M, K, Kp, N, ldx, ldy, relu;
     const int* d_m;    // may be NULL: rows >= *d_m are skipped
+    unsigned long long* clock_probe = nullptr;   // tools/ (DODT_FC_CLOCK=1): shader and 100 MHz clock of one workgroup's K loop
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -462,10 +463,17 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     };
     issue(0, 0);
     if (nstages > 1) issue(1, 1);
+    const bool probe = a.clock_probe != nullptr && blockIdx.x == 17 && tid == 0;
+    unsigned long long c0 = 0, r0 = 0;
+    if (probe) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int st = 0; st < nstages; st += 3) {
         stage(std::integral_constant<int, 0>{}, st);
         if (st + 1 < nstages) stage(std::integral_constant<int, 1>{}, st + 1);
         if (st + 2 < nstages) stage(std::integral_constant<int, 2>{}, st + 2);
+    }
+    if (probe) {
+        a.clock_probe[0] = __builtin_amdgcn_s_memtime() - c0;
+        a.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     // epilogue: bias + activation; lane = feature, registers = samples
 #pragma unroll
@@ -484,7 +492,16 @@ fc_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     }
 }
 
-int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
+int launch_fc_dma(hipStream_t s, const GemmArgs& a_in, int Npad) {
+    GemmArgs a = a_in;
+    // DODT_FC_CLOCK=1 (tools/gemm_one.py): shader clock inside the K loop of workgroup 17, from s_memtime against the
+    // 100 MHz s_memrealtime -- the clock the fp32 matrix pipe actually runs at under this kernel
+    static const bool want_clock = getenv("DODT_FC_CLOCK") != nullptr;
+    static unsigned long long* d_probe = nullptr;
+    if (want_clock) {
+        if (!d_probe) DODT_HIP_CHECK(hipMalloc(&d_probe, 2 * sizeof(unsigned long long)));
+        a.clock_probe = d_probe;
+    }
     // 64 x 128 tiles (two MFMA tiles per wave) when that still gives two workgroups per CU
     static const int force_nt = getenv("DODT_FC_NT") ? atoi(getenv("DODT_FC_NT")) : 0;
     const int nt = force_nt ? force_nt
@@ -511,6 +528,14 @@ int launch_fc_dma(hipStream_t s, const GemmArgs& a, int Npad) {
     else e = go(&fc_dma_kernel<false, 1>, (size_t)kDmaStages * (kDmaXFloats + kDmaBK * 64) * 4);
     DODT_HIP_CHECK(e);
     DODT_LAUNCH_CHECK();
+    if (want_clock) {
+        unsigned long long h[2] = {0, 0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost);
+        if (h[1])
+            fprintf(stderr, "[dodt] fc_dma_kernel M %d K %d N %d: K loop of workgroup 17: %llu shader cycles in %.2f us = %.3f GHz\n",
+                    a.M, a.K, a.N, h[0], h[1] / 100.0, (double)h[0] / h[1] * 0.1);
+    }
     return DODT_OK;
 }
 
