@@ -452,27 +452,23 @@ def test_pair_free_running_by_conv_mode(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    hp = synth.head_params()
-    w = synth.pipeline_weights(C)
     tols = (1e-4, 1e-3, 1e-2, 5e-2)
-    oracle = []          # per pair: {arithmetic: (feats, detections)}
-    for k, (seq, frames) in enumerate(FREE_RUNNING_PAIRS):
-        pts = [synth.lidar_frame(seq, f) for f in frames]
-        imgs = [synth.image_frame(seq, f) for f in frames]
-        inps = [opipe.frame_inputs(p, C, synth.R0_RECT, synth.TR_VELO_TO_CAM, synth.P2, synth.IMAGE_WH)
-                for p in pts]
-        row = {}
-        for name in (('f32', 'exact') if k == 0 else ('exact',)):
-            if name == 'exact':
-                with tfops.exact_sums():
-                    feats = [opipe.extract(inps[j]['bev'], imgs[j], w['bev_params'], w['img_params'],
-                                           C['img_dims']) for j in range(2)]
-            else:
-                feats = [opipe.extract(inps[j]['bev'], imgs[j], w['bev_params'], w['img_params'],
-                                       C['img_dims']) for j in range(2)]
-            row[name] = (feats if k == 0 else None,
-                         opipe.pair_detections_computed(inps, feats, hp, C, synth.P2, synth.IMAGE_WH, 1024))
-        oracle.append(row)
+    # the device runs (one child process per form, all three started now) proceed beside the oracle's (one worker
+    # process per pair and arithmetic, tests/_oracle_jobs.py): 150 s in a row, about a third of it side by side
+    children = []
+    for label, mode in FREE_RUNNING_MODES:
+        out = str(tmp_path / ('fr_%s.npz' % mode))
+        children.append((label, mode, out, subprocess.Popen(
+            [sys.executable, '-c', _CHILD % (root, FREE_RUNNING_PAIRS), out], env=dict(os.environ, DODT_CONV_WINO=mode),
+            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    import multiprocessing as mp
+    from _oracle_jobs import free_running_pair
+    jobs = [(seq, frames, 'exact', 3, k == 0) for k, (seq, frames) in enumerate(FREE_RUNNING_PAIRS)] + \
+           [(FREE_RUNNING_PAIRS[0][0], FREE_RUNNING_PAIRS[0][1], 'f32', 3, True)]
+    with mp.get_context('spawn').Pool(len(jobs)) as pool:
+        res = pool.map(free_running_pair, jobs)
+    oracle = [{'exact': res[k]} for k in range(len(FREE_RUNNING_PAIRS))]      # per pair: {arithmetic: (BEV maps, detections)}
+    oracle[0]['f32'] = res[-1]
 
     def agreement(got_top, got_rec, ref):
         n_ref = len(ref['det_idx'])
@@ -491,12 +487,9 @@ def test_pair_free_running_by_conv_mode(tmp_path):
     table['oracle f32'] = {'exact': [agreement(o32[f]['top_anchors'], o32[f]['records'][:len(o32[f]['det_idx'])], oex[f])
                                      for f in range(2)]}
     default_mode = None
-    for label, mode in FREE_RUNNING_MODES:
-        out = str(tmp_path / ('fr_%s.npz' % mode))
-        r = subprocess.run([sys.executable, '-c', _CHILD % (root, FREE_RUNNING_PAIRS), out],
-                           env=dict(os.environ, DODT_CONV_WINO=mode), capture_output=True, text=True,
-                           timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for label, mode, out, proc in children:
+        log, _ = proc.communicate(timeout=900)
+        assert proc.returncode == 0, log[-3000:]
         got = np.load(out)
         assert int(got['mode']) == int(mode)
         row = {'f32': [agreement(got['p0_top%d' % f], got['p0_rec%d' % f], oracle[0]['f32'][1][f]) for f in range(2)],
@@ -508,7 +501,7 @@ def test_pair_free_running_by_conv_mode(tmp_path):
         for base in ('f32', 'exact'):
             ferr, cerr = [], []
             for f in range(2):
-                ref_map = oracle[0][base][0][f][0]
+                ref_map = oracle[0][base][0][f]
                 sc = np.abs(ref_map).max()
                 ferr.append(float(np.abs(got['feat%d' % f] - ref_map).max() / sc))
                 want = tfops.crop_and_resize(ref_map, got['top_bev%d' % f], 7, 7)
