@@ -869,11 +869,13 @@ def main():
             out['cpu_baseline'] = baseline
         print(json.dumps(out))
         sys.stdout.flush()
+    arm(600, 'the closing barrier')
     if comm is not None:
         comm.barrier()
         comm.close()
     if host_sync is not None:
         host_sync.close()
+    disarm()
 
 
 if __name__ == '__main__':
