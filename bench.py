@@ -427,7 +427,9 @@ def main():
 
         # a small ring of distinct synthetic batches, resident in HBM before timing starts;
         # every pair of a batch comes from a different sequence (they are independent)
-        n_batches = 2
+        # (three per rank: at N = 8 the ranks together draw 24 sequences -- BASELINE.json configs[3]'s
+        #  "synthetic 21-sequence stream")
+        n_batches = 3
         batches = []
         for i in range(n_batches):
             pts, imgs, heads = [], [], []
