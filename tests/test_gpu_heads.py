@@ -31,7 +31,10 @@ def _close(got, want, tol=1e-4):
 
 
 @pytest.mark.parametrize('hw,md,s2,pad', [((20, 24), 5, 2, 5), ((37, 19), 2, 1, 3),
-                                          ((16, 16), 2, 2, 2), ((33, 70), 5, 2, 5)])
+                                          ((16, 16), 2, 2, 2), ((33, 70), 5, 2, 5),
+                                          # the 5 x 5 grid with the output shifted against the input (pad != max
+                                          # displacement: a larger and a smaller output than the input), ragged tiles
+                                          ((25, 40), 4, 2, 5), ((18, 33), 5, 2, 3), ((130, 150), 5, 2, 5)])
 def test_correlation_matches_oracle(ctx, hw, md, s2, pad):
     rng = np.random.default_rng(hw[0] * 100 + md)
     a = rng.normal(size=(1,) + hw + (32,)).astype(np.float32)
