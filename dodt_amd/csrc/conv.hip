@@ -162,8 +162,20 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         // the small maps: slower, the per-item cost grows faster than the balance improves)
         long best_n = 0;
         static const long per_cu = getenv("DODT_CONV_BF16_ITEMS_PER_CU") ? atol(getenv("DODT_CONV_BF16_ITEMS_PER_CU")) : 4;
+        // 8-row tiles (three workgroups per CU) only where the 16-row tiles give fewer than 1.6 items per CU -- the
+        // 88 x 100 / 45 x 150 maps of the deepest level: conv4_2 34 -> 30 us, stacks 1.065 -> 1.043 ms alone, nothing in
+        // the pipeline; at 1.9 items per CU (the image net's level 3, 480 items) they are slower: 26 -> 29 us
+        // (DODT_CONV_BF16_MT2=0: never; DODT_CONV_BF16_MT2_BELOW=<items>: another threshold)
+        static const bool mt2 = !(getenv("DODT_CONV_BF16_MT2") && atoi(getenv("DODT_CONV_BF16_MT2")) == 0);
+        static const long mt2_below = getenv("DODT_CONV_BF16_MT2_BELOW") ? atol(getenv("DODT_CONV_BF16_MT2_BELOW")) : 0;
+        long n16 = 0;
+        for (size_t i = 0; i < vs.size(); ++i)
+            if (vs[i].dma && vs[i].TH == 16 && Cout % vs[i].BN == 0)
+                n16 = std::max(n16, (long)dodt::ceil_div(H, 16) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch);
+        const bool want_mt2 = mt2 && n16 < (mt2_below > 0 ? mt2_below : 8L * num_cus / 5);
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].dma || Cout % vs[i].BN != 0) continue;
+            if ((vs[i].TH == 8) != want_mt2) continue;
             const long n = (long)dodt::ceil_div(H, vs[i].TH) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch;
             const bool enough = n >= per_cu * num_cus, best_enough = best_n >= per_cu * num_cus;
             if (best < 0 || (enough && !best_enough) || (enough && best_enough && vs[i].BN > vs[best].BN) ||

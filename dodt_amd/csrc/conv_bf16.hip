@@ -30,6 +30,7 @@ std::vector<KernelVariant> bf16_variants() {
         // round 2: LDS-DMA staged 3x3 stride-1 kernels, 16 x 32 px x 64 / 32 channels
         InstBf16Dma<4, 2, 2>::variant(),
         InstBf16Dma<4, 1, 2>::variant(),
+        InstBf16Dma<2, 1, 2>::variant(),      // round 4: 8 x 32 px x 32 channels, three workgroups per CU
         // round 3: the LDS-DMA staged transposed conv on v_mfma_f32_16x16x16_bf16 (deconv_kernel.h)
         InstDeconvDma<2, true>::variant(),
         InstDeconvDma<1, true>::variant(),

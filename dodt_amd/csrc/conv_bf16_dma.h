@@ -52,8 +52,10 @@ struct Bf16DmaCfg {
     static_assert(MT % 2 == 0, "the fused pool pairs the rows of a wave");
 };
 
+// (MT = 2: 8-row tiles, 41 KB, three workgroups per CU -- for the small maps of the deepest level, whose 16-row
+//  tiles do not give every CU two workgroups)
 template <int MT, int NT, int S>
-__global__ void __launch_bounds__(256, (S == 2 ? 2 : 1))
+__global__ void __launch_bounds__(256, (S == 2 ? (MT == 2 ? 3 : 2) : 1))
 conv3x3_bf16_dma_kernel(const ConvArgs a) {
     using Cfg = Bf16DmaCfg<MT, NT, S>;
     constexpr int BN = Cfg::BN, PW = Cfg::PW;

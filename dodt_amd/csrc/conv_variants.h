@@ -128,7 +128,8 @@ struct InstBf16Dma {
     }
     static KernelVariant variant() {
         int per_cu = (160 * 1024) / Cfg::kLdsBytes;
-        if (per_cu > (S == 2 ? 2 : 1)) per_cu = (S == 2 ? 2 : 1);
+        constexpr int kMax = S == 2 ? (MT == 2 ? 3 : 2) : 1;      // the kernel's launch bounds
+        if (per_cu > kMax) per_cu = kMax;
         KernelVariant v{Cfg::TW, 4 * MT, 4, 1, Cfg::BN, 16, false, false, Cfg::TH, Cfg::kLdsBytes,
                         per_cu, &launch, &prepare};
         v.bf16 = true;

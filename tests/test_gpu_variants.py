@@ -19,6 +19,9 @@ VARIANTS = [
     ({'DODT_CORR_HALVES': '2'}, ['tests/test_gpu_heads.py', '-k', 'correlation']),
     ({'DODT_CORR_TWO_PASS': '1'}, ['tests/test_gpu_heads.py', '-k', 'correlation']),
     # one work queue per launch instead of one per group of blocks that share an XCD
+    # bf16 convs: 16-row tiles also where the map gives fewer than 1.6 items per CU (the small test maps otherwise
+    # all take the 8-row tiles)
+    ({'DODT_CONV_BF16_MT2': '0'}, ['tests/test_gpu_conv_bf16.py']),
     ({'DODT_CONV_BF16_XCD': '0', 'DODT_CONV_F32_XCD': '0'},
      ['tests/test_gpu_conv_bf16.py', 'tests/test_gpu_conv.py', '-k', 'not other_fp32']),
 ]
