@@ -160,6 +160,11 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         // the widest channel tile that still leaves four items per CU (two resident workgroups,
         // two rounds); if none does, the one with the most items (half-height tiles were tried for
         // the small maps: slower, the per-item cost grows faster than the balance improves)
+        // the level-1 layers (32 output channels, 2 / 4 chunks): the streaming kernel (DODT_CONV_BF16_STREAM=0: not)
+        static const bool stream = !(getenv("DODT_CONV_BF16_STREAM") && atoi(getenv("DODT_CONV_BF16_STREAM")) == 0);
+        if (stream && Cout == 32)
+            for (size_t i = 0; i < vs.size(); ++i)
+                if (vs[i].stream_nch > 0 && vs[i].stream_nch * 16 == Cin) return (int)i;
         long best_n = 0;
         static const long per_cu = getenv("DODT_CONV_BF16_ITEMS_PER_CU") ? atol(getenv("DODT_CONV_BF16_ITEMS_PER_CU")) : 4;
         // 8-row tiles (three workgroups per CU) only where the 16-row tiles give fewer than 1.6 items per CU -- the
@@ -170,11 +175,11 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         static const long mt2_below = getenv("DODT_CONV_BF16_MT2_BELOW") ? atol(getenv("DODT_CONV_BF16_MT2_BELOW")) : 0;
         long n16 = 0;
         for (size_t i = 0; i < vs.size(); ++i)
-            if (vs[i].dma && vs[i].TH == 16 && Cout % vs[i].BN == 0)
+            if (vs[i].dma && !vs[i].stream_nch && vs[i].TH == 16 && Cout % vs[i].BN == 0)
                 n16 = std::max(n16, (long)dodt::ceil_div(H, 16) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch);
         const bool want_mt2 = mt2 && n16 < (mt2_below > 0 ? mt2_below : 8L * num_cus / 5);
         for (size_t i = 0; i < vs.size(); ++i) {
-            if (!vs[i].dma || Cout % vs[i].BN != 0) continue;
+            if (!vs[i].dma || vs[i].stream_nch || Cout % vs[i].BN != 0) continue;
             if ((vs[i].TH == 8) != want_mt2) continue;
             const long n = (long)dodt::ceil_div(H, vs[i].TH) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch;
             const bool enough = n >= per_cu * num_cus, best_enough = best_n >= per_cu * num_cus;
@@ -435,7 +440,7 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
         a.debug = dbg;
         // DODT_CONV_STAMP_LAYER=<name>: in-kernel step stamps of that layer's launch (diagnostic)
         static const char* stamp_layer = getenv("DODT_CONV_STAMP_LAYER");
-        if (stamp_layer && l.name == stamp_layer) a.debug |= 32;
+        if (stamp_layer && l.name == stamp_layer) a.debug |= 32;     // (+ DODT_CONV_DEBUG=64: the streaming kernel's producer wave)
     }
     a.counter = ex->d_counters + 2 * (&l - ex->layers.data()) + which;
     a.counter_base = ex->d_counters + 64;
@@ -543,6 +548,7 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
 const char* kernel_name(const KernelVariant& v) {
     if (v.wino) return v.wino_m == 4 ? "wino43_f32_kernel" : "wino3x3_f32_kernel";
     if (v.deconv_dma) return "deconv3x3_dma_kernel";
+    if (v.stream_nch) return "conv3x3_bf16_stream_kernel";
     if (v.dma) return "conv3x3_bf16_dma_kernel";
     if (v.small_cin) return "conv3x3_small_cin_kernel";
     return "conv3x3_mfma_kernel";

@@ -31,6 +31,9 @@ std::vector<KernelVariant> bf16_variants() {
         InstBf16Dma<4, 2, 2>::variant(),
         InstBf16Dma<4, 1, 2>::variant(),
         InstBf16Dma<2, 1, 2>::variant(),      // round 4: 8 x 32 px x 32 channels, three workgroups per CU
+        // round 4: producer wave + weights in registers, for the level-1 layers (32 output channels, 2 / 4 chunks)
+        InstBf16Stream<2, 2, 8>::variant(),
+        InstBf16Stream<2, 4, 7>::variant(),
         // round 3: the LDS-DMA staged transposed conv on v_mfma_f32_16x16x16_bf16 (deconv_kernel.h)
         InstDeconvDma<2, true>::variant(),
         InstDeconvDma<1, true>::variant(),

@@ -329,4 +329,344 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4, late: the level-1 layers (32 output channels, 32 or 64 input channels: conv1_2, pyramid_fusion1 -- 0.25 of
+// the bf16 stacks' time) are HBM-bound at ~3 TB/s with the kernel above: it has ONE 20 KB chunk per workgroup on its
+// way (two per CU = 40 KB against the ~60 KB per CU that 5 TB/s times the loaded memory latency asks for), and a
+// deeper ring does not help it, because a wave's epilogue stores sit between its copies in the same in-order counter
+// (vmcnt): the first wait after an epilogue drains everything older.  This kernel separates the roles instead:
+//   * wave 3 is the PRODUCER: it alone issues the LDS-DMA copies (a ring of S patch images, S - 1 chunks ahead of the
+//     MFMAs), has nothing else in its vmcnt queue, and so can wait for exactly "chunk k + 1 has landed"
+//     (vmcnt((S - 2) x copies per chunk)) before the barrier that ends step k;
+//   * waves 0-2 are the CONSUMERS: MT rows of 32 pixels each (tile = 3 MT rows x 32 pixels), weights for ALL chunks in
+//     registers (9 NCH fragments of 16 bytes per lane, loaded once per persistent workgroup: no weight image, no
+//     weight copies, no weight reads from LDS), epilogue as above;
+//   * the work queue is the grouped one above; the tickets are drawn by lane 0 of wave 0 (whose vmcnt queue holds its
+//     stores only) and published through a 16-entry ring in LDS, D items ahead.
+// MT = 2, S = 8: 6 x 32 pixel tiles, 9 KB images, 72 KB of LDS, two workgroups per CU, 7 x 8.7 KB in flight each.
+template <int MT, int NCH, int S>
+struct Bf16StreamCfg {
+    static constexpr int TW = 32, TH = 3 * MT, BN = 32;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int kPatchSlots = PH * PW * 2;                 // 16-byte slots
+    static constexpr int kCopies = (kPatchSlots + 63) / 64;         // 1 KB copies per chunk, all by the producer
+    static constexpr int kPatchFloats = kCopies * 256;
+    static constexpr int kWFloats = 9 * 2 * BN * 4;                 // a chunk's weights in global memory: [tap][h][n][16 B]
+    static constexpr int WR = NCH <= 3 ? NCH : 3;                   // chunks whose weights stay in registers (36 each); the others' in LDS
+    static constexpr int kWLdsFloats = (NCH - WR) * kWFloats;
+    static constexpr int kLdsBytes = S * kPatchFloats * 4 + 64 + 384 + kWLdsFloats * 4;     // images | item ring | scale, shift, bottleneck weights | weights
+    static constexpr int kAhead = (NCH - 1 + S) / NCH + 3;          // D: the prologue publishes ring entries 0 .. D - 2, item n >= 1 entry n + D - 2
+    static_assert((S - 2) * kCopies <= 63, "vmcnt is six bits");
+    static_assert(MT % 2 == 0, "the fused pool pairs the rows of a wave");
+    static_assert(kAhead <= 8, "item ring");
+};
+
+template <int MT, int NCH, int S>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_bf16_stream_kernel(const ConvArgs a) {
+    using Cfg = Bf16StreamCfg<MT, NCH, S>;
+    constexpr int BN = Cfg::BN, PW = Cfg::PW, D = Cfg::kAhead, KC = Cfg::kCopies;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* s_q = reinterpret_cast<int*>(smem + S * Cfg::kPatchFloats);      // item ring: entry n & 15 = this workgroup's n-th item
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave == 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int in_plane = a.H * a.W * 8;          // floats per CB16 plane (32 B per pixel)
+    const int plane_bytes = in_plane * 4;
+
+    // item -> tile, by arithmetic on the table's order (frame, tile row, tile column; one channel tile): the producer must
+    // not load from memory (a vector load's wait would drain its copy ring), and the consumers need not
+    struct Item { int frame, ty0, tx0; };
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    auto decode = [&](int it) {
+        it = __builtin_amdgcn_readfirstlane(it);
+        const int f = it / tiles_per_frame, r = it - f * tiles_per_frame;
+        const int ty = r / a.tiles_x;
+        return Item{f, ty * Cfg::TH, (r - ty * a.tiles_x) * Cfg::TW};
+    };
+    // the grouped queue of conv3x3_bf16_dma_kernel
+    const bool grouped = a.xcd_counters != nullptr;
+    const int vx = grouped ? (int)(blockIdx.x & 7) : 0;
+    const int q_lo = grouped ? vx * (a.n_items / 8) + min(vx, a.n_items % 8) : 0;
+    const int q_hi = grouped ? q_lo + a.n_items / 8 + (vx < a.n_items % 8 ? 1 : 0) : a.n_items;
+    const int q_blocks = grouped ? ((int)gridDim.x - vx + 7) / 8 : (int)gridDim.x;
+    const int q_first = q_lo + q_blocks;
+    int* const q_counter = grouped ? a.xcd_counters + 16 * vx : a.counter;
+    auto ticket_item = [&](int t) { return q_first + t < q_hi ? q_first + t : a.n_items; };
+    const int k_first = q_lo + (grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    if (k_first >= q_hi) return;
+    // batch-norm scale / shift and the bottleneck's weights of the 32 output channels: in LDS, so that an item's epilogue
+    // does not wait for global loads (an item is 1-2 us of MFMAs here)
+    float* s_par = reinterpret_cast<float*>(s_q + 16);
+    if (tid < 96) s_par[tid] = tid < 32 ? a.scale[tid] : tid < 64 ? a.shift[tid - 32] : a.bneck_w ? a.bneck_w[tid - 64] : 0.0f;
+    auto queue_at = [&](int n) { return __builtin_amdgcn_readfirstlane(s_q[n & 15]); };
+
+    // items 0 .. D-2 of this workgroup: the first by its block index, the others by one draw of D - 2 tickets
+    if (tid == 0) {
+        s_q[0] = k_first;
+        if (D > 2) {
+            const int t = atomicAdd(q_counter, D - 2);
+#pragma unroll
+            for (int i = 0; i < D - 2; ++i) s_q[1 + i] = ticket_item(t + i);
+        }
+    }
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+
+    if (producer) {
+        // ---- wave 3: the copy stream -----------------------------------------------------------------------
+        int p_off[KC];
+        i32x4_t in_rsrc;
+        auto setup = [&](int item) {
+            if (item >= a.n_items) {      // nothing left: the remaining copies read zeros (they keep the count exact)
+                in_rsrc = make_rsrc(a.in, 0u);
+                return;
+            }
+            const Item it = decode(item);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int s = k * 64 + lane;
+                const int q = s >> 1;
+                const int py = q / PW, px = q - py * PW;
+                const int half = (s & 1) ^ ((px >> 3) & 1);
+                const int gy = it.ty0 - 1 + py, gx = it.tx0 - 1 + px;
+                const bool ok = py < Cfg::PH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                p_off[k] = ok ? ((gy * a.W + gx) * 8 + half * 4) * 4 : kOob;
+            }
+            const float* in_item = a.in + (size_t)it.frame * a.in_frame_stride + (size_t)(a.in_coff / 16) * in_plane;
+            in_rsrc = make_rsrc(in_item, (a.debug & 2) ? 0u : (unsigned)(NCH * plane_bytes));     // (tools/: 2 = no loads)
+        };
+        int c_n = 0, c_ch = 0, c_slot = 0;       // the cursor: item sequence number, chunk, ring slot
+        auto copies = [&]() {
+            const unsigned img = lds0 + (unsigned)(c_slot * Cfg::kPatchFloats) * 4;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) blds16s(in_rsrc, p_off[k], c_ch * plane_bytes, img + k * 1024);
+            c_slot = c_slot + 1 == S ? 0 : c_slot + 1;
+        };
+        auto advance = [&]() {       // (behind a barrier: the ring entry it may read was published before it)
+            if (++c_ch == NCH) {
+                c_ch = 0;
+                ++c_n;
+                setup(queue_at(c_n));
+            }
+        };
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_barrier" ::: "memory");             // B0: the item ring is visible
+        setup(k_first);
+#pragma unroll 1
+        for (int b = 0; b < S - 1; ++b) {
+            copies();
+            advance();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * KC) : "memory");      // chunk 0 has landed
+        asm volatile("s_barrier" ::: "memory");             // B1
+        for (int n = 0; queue_at(n) < a.n_items; ++n) {
+            // (stamps, producer's view: item top | first copies issued | first wait over | first barrier over | last barrier over | set-up done)
+            const bool stamp = (a.debug & 32) && (a.debug & 64) && blockIdx.x == 1 && lane == 0 && n < 12;
+            int* stamps = a.counter_base + 32 + (n < 12 ? n : 0) * 6;
+            if (stamp) stamps[0] = (int)__builtin_amdgcn_s_memtime();
+#pragma unroll 1
+            for (int ch = 0; ch < NCH; ++ch) {
+                copies();                          // chunk k + S - 1 into the image step k - 1 released
+                if (stamp && ch == 0) stamps[1] = (int)__builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * KC) : "memory");      // chunk k + 1 has landed
+                if (stamp && ch == 0) stamps[2] = (int)__builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                if (stamp && ch == 0) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+                if (stamp && ch == NCH - 1) stamps[4] = (int)__builtin_amdgcn_s_memtime();
+                advance();
+            }
+            if (stamp) stamps[5] = (int)__builtin_amdgcn_s_memtime();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may land in this LDS after the workgroup has left
+        return;
+    }
+
+    // ---- waves 0-2: weights in registers, MFMAs, epilogue ---------------------------------------------------
+    constexpr int WR = Cfg::WR;
+    f32x4 wreg[WR * 9];
+    const int w_lane = (lh * BN + li) * 4;
+    {
+        const float* wl = a.w + w_lane;
+#pragma unroll
+        for (int i = 0; i < WR * 9; ++i)
+            wreg[i] = *reinterpret_cast<const f32x4*>(wl + (size_t)(i / 9) * Cfg::kWFloats + (i % 9) * 2 * BN * 4);
+    }
+    float* s_w = s_par + 96;          // the weights of chunks WR .. NCH - 1, as they lie in global memory
+    for (int i = tid; i < Cfg::kWLdsFloats / 4; i += 192)
+        reinterpret_cast<f32x4*>(s_w)[i] = reinterpret_cast<const f32x4*>(a.w + (size_t)WR * Cfg::kWFloats)[i];
+    int col_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int c = li + kx;
+        col_off[kx] = c * 8 + ((lh ^ ((c >> 3) & 1)) * 4);
+    }
+    const int row0 = wave * MT * PW * 8;
+    auto mfma_acc = [&](const f32x4& w, const f32x4& x, f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
+    };
+    auto mfma_first = [&](const f32x4& w, const f32x4& x, f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(w), "v"(x));
+    };
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int i = 0; i < WR * 9; ++i) asm volatile("" : "+v"(wreg[i]));
+    asm volatile("s_barrier" ::: "memory");                 // B0
+    asm volatile("s_barrier" ::: "memory");                 // B1: chunk 0 is in image 0
+    int slot = 0, ticket = 0;
+    for (int n = 0;; ++n) {
+        const int item = queue_at(n);
+        if (item >= a.n_items) break;
+        // (a.debug & 32, tools/: s_memtime stamps of the first 12 items of block 1 -- wave 0's view, or with a.debug & 64 the
+        //  producer's: item top | first step done | last step done | stores issued | pool issued)
+        const bool stamp = (a.debug & 32) && !(a.debug & 64) && blockIdx.x == 1 && tid == 0 && n < 12;
+        int* stamps = a.counter_base + 32 + (n < 12 ? n : 0) * 6;
+        if (stamp) stamps[0] = (int)__builtin_amdgcn_s_memtime();
+        f32x16 acc[MT];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            // queue tickets: at the top of every item's last step the ticket drawn an item ago is published (visible behind
+            // this step's barrier) and the next one drawn -- an atomic's round trip is longer than a step, and the compiler's
+            // wait for the result also waits for the wave's stores, which are an item old by then
+            if (ch == NCH - 1 && tid == 0) {
+                if (n >= 1) s_q[(n + D - 2) & 15] = ticket_item(ticket);
+                ticket = atomicAdd(q_counter, 1);
+            }
+            const float* sP = smem + slot * Cfg::kPatchFloats + row0;
+            const float* sW = s_w + (ch >= WR ? (ch - WR) * Cfg::kWFloats : 0) + w_lane;
+            f32x4 x[MT + 2], wl[2];
+#pragma unroll
+            for (int r = 0; r < MT + 2; ++r) x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[0]);
+            if (ch >= WR) wl[0] = *reinterpret_cast<const f32x4*>(sW);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(a.debug & 4) || ch == 0)                // (tools/: 4 = the first chunk's MFMAs only)
+#pragma unroll
+            for (int g9 = 0; g9 < 9; ++g9) {             // group g9 = kx * 3 + ky
+                const int kx = g9 / 3, ky = g9 % 3;
+                if (ch >= WR && g9 + 1 < 9)              // the next tap's fragment, one group ahead
+                    wl[(g9 + 1) & 1] = *reinterpret_cast<const f32x4*>(sW + (((g9 + 1) % 3) * 3 + (g9 + 1) / 3) * 2 * BN * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4& w = ch >= WR ? wl[g9 & 1] : wreg[(ch < WR ? ch : 0) * 9 + ky * 3 + kx];
+                    if (ch == 0 && g9 == 0) mfma_first(w, x[mt + ky], acc[mt]);
+                    else mfma_acc(w, x[mt + ky], acc[mt]);
+                }
+                if (ky == 2 && kx < 2) {
+#pragma unroll
+                    for (int r = 0; r < MT + 2; ++r)
+                        x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[kx + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this step's LDS reads and the ring entry are done
+            asm volatile("s_barrier" ::: "memory");
+            slot = slot + 1 == S ? 0 : slot + 1;
+            if (stamp && ch == 0) stamps[1] = (int)__builtin_amdgcn_s_memtime();
+            if (stamp && ch == NCH - 1) stamps[2] = (int)__builtin_amdgcn_s_memtime();
+        }
+        // the asm MFMAs are opaque to the hazard recogniser: 16-pass results need 18 wait states
+#pragma unroll
+        for (int k = 0; k < MT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
+        // ---- epilogue: batch-norm + ReLU, stores, fused 2x2 pool / 1x1 bottleneck -- what store_tile / pool_tile of
+        // conv_kernels.h do for the other kernels, with the per-channel parameters read from LDS in one batch (an item is
+        // 1-2 us here: eight dependent parameter loads per tile were twice the MFMAs' time) and the pool's horizontal
+        // neighbour taken by DPP
+        const Item cur = decode(item);
+        auto epilogue = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;     // 0: CB16 bf16 map, 1: the same + its 2x2 max pool, 2: NHWC fp32 (+ bottleneck)
+            const float floor_v = a.relu ? 0.0f : -3.0e38f;
+            {
+                f32x4 sc[4], sh[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = group_channel<true>(g, lh);
+                    sc[g] = *reinterpret_cast<const f32x4*>(s_par + c);
+                    sh[g] = *reinterpret_cast<const f32x4*>(s_par + 32 + c);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mt][r] = fmaxf(acc[mt][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], floor_v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int out_rows = a.H - a.out_y0;
+            const long long plane = (long long)out_rows * a.W * 8;
+            float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
+            const int x = cur.tx0 + li;
+            f32x4 bw[4];      // (read when the scales are dead: the 64-channel instance has 144 registers of weights)
+            if (MODE == 2 && a.bneck_w) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bw[g] = *reinterpret_cast<const f32x4*>(s_par + 64 + group_channel<true>(g, lh));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int y = cur.ty0 + wave * MT + mt;
+                const bool ok = y < a.H && x < a.W && y >= a.out_y0 && !(a.debug & 1);      // (tools/: 1 = no stores)
+                const size_t px = (size_t)(y - a.out_y0) * a.W + x;
+                if (MODE == 2) {
+                    if (ok) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(out + px * a.out_ld + a.out_coff + group_channel<true>(g, lh)) =
+                                f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                    }
+                    if (a.bneck_w) {
+                        float dot = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dot += acc[mt][r] * bw[r >> 2][r & 3];
+                        dot += __shfl_xor(dot, 32, 64);          // the other 16 channels of this pixel live in lane ^ 32
+                        if (ok && lh == 0)
+                            a.bneck_out[(size_t)cur.frame * a.bneck_frame_stride + px] =
+                                fmaxf(dot * a.bneck_scale + a.bneck_shift, 0.0f);
+                    }
+                } else if (ok) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)       // groups (2 gp, 2 gp + 1): 8 consecutive channels = one 16-byte store
+                        *reinterpret_cast<f32x4*>(out + (size_t)((a.out_coff + 16 * gp) >> 4) * plane + px * 8 + 4 * lh) =
+                            f32x4{pack_bf16(acc[mt][8 * gp], acc[mt][8 * gp + 1]), pack_bf16(acc[mt][8 * gp + 2], acc[mt][8 * gp + 3]),
+                                  pack_bf16(acc[mt][8 * gp + 4], acc[mt][8 * gp + 5]), pack_bf16(acc[mt][8 * gp + 6], acc[mt][8 * gp + 7])};
+                }
+            }
+            if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+            if (MODE == 1) {
+                // VALID 2x2 pool of the activated rows (mt, mt + 1): vertical neighbour = the same lane of the next row,
+                // horizontal = lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes at even (y, x) store
+                const int OW = a.W >> 1;
+                const long long pplane = (long long)(a.H >> 1) * OW * 8;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt += 2) {
+                    const int y = cur.ty0 + wave * MT + mt;
+                    const bool writer = y < a.H && x < a.W && !(y & 1) && !(x & 1) && y + 1 < a.H && x + 1 < a.W && !(a.debug & 1);
+                    float m[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = fmaxf(acc[mt][r], acc[mt + 1][r]);
+                        const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
+                        m[r] = fmaxf(t, o);
+                    }
+                    if (writer) {
+                        float* base = a.pool_out + (size_t)cur.frame * a.pool_frame_stride +
+                                      ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp)
+                            *reinterpret_cast<f32x4*>(base + (size_t)gp * pplane) =
+                                f32x4{pack_bf16(m[8 * gp], m[8 * gp + 1]), pack_bf16(m[8 * gp + 2], m[8 * gp + 3]),
+                                      pack_bf16(m[8 * gp + 4], m[8 * gp + 5]), pack_bf16(m[8 * gp + 6], m[8 * gp + 7])};
+                    }
+                }
+            }
+        };
+        if (a.pool_out) epilogue(std::integral_constant<int, 1>{});
+        else if (!a.out_nhwc) epilogue(std::integral_constant<int, 0>{});
+        else epilogue(std::integral_constant<int, 2>{});
+        if (stamp) { stamps[4] = (int)__builtin_amdgcn_s_memtime(); stamps[5] = stamps[4]; }
+    }
+}
+
 }  // namespace dodt

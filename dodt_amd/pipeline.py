@@ -409,8 +409,20 @@ class FramePairPipeline(object):
             self._tail(self.pending)
             p_sides, p_preps = self._streams(self.pending['cur'])
             for i, s in enumerate(p_sides):
-                main.wait_for(s)       # previous step's records are complete on `main`
-                p_preps[i].wait_for(s)   # the next step of that parity reuses that tail's buffers: its prep waits
+                # one event at the tail's end, three waiters: `main` (the previous step's records are complete there, and
+                # the BEV stack of the next step of that parity overwrites the maps the tail reads), the image stream (the
+                # same for the image net's maps: without look-ahead that wait is implied -- the next prep sits behind the
+                # tail on the side stream and the conv streams wait for the prep --, with look-ahead the prep is in front
+                # of it), and a prep stream of its own, if any.  (A mark after the tail's LAST READ of the image maps
+                # instead -- its stage-2 crops -- was measured: the extra event inside the tail's launch chain costs more
+                # than the earlier release returns, 868 against 899 pairs/s with the bf16 path; DODT_PIPE_IMG_WAIT=none is
+                # the racy form the first look-ahead build had, 907.)
+                s.mark(self.TAIL_DONE_MARK)
+                main.wait_mark(s, self.TAIL_DONE_MARK)
+                if os.environ.get('DODT_PIPE_IMG_WAIT', 'tail') != 'none':
+                    self.img_ctx.wait_mark(s, self.TAIL_DONE_MARK)
+                if p_preps[i] is not s:
+                    p_preps[i].wait_mark(s, self.TAIL_DONE_MARK)
         self.pending = dict(cur=cur, heads=heads, step=k, rslot=k % len(self.rec2))
         # The tail of THIS step (next call) starts when these convs are done.  The point is marked now and waited
         # for when the tail is enqueued -- behind the NEXT step's prep on the same side stream, which therefore
@@ -599,6 +611,7 @@ class FramePairPipeline(object):
             drain(g0)                           # waits for CORR_ROIS_MARK: correlation head, NMS #2, records
 
     PROPOSALS_MARK, CORR_ROIS_MARK = 252, 253   # mark slots of the side contexts (the T branch's hand-overs)
+    TAIL_DONE_MARK = 247                        # ... : the end of a step's tail on that stream
 
     def sync(self):
         self.ctx.sync()
