@@ -112,6 +112,7 @@ SIGNATURES = {
                                             C.POINTER(_i), C.POINTER(_i),
                                             C.POINTER(_i)]),
     'dodt_extractor_output_shape': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'dodt_extractor_first_layers_folded': (_i, [_vp]),
     'dodt_extractor_flops': (_d, [_vp]),
     'dodt_extractor_mfma_flops': (_d, [_vp]),
     'dodt_extractor_bytes': (_d, [_vp]),

@@ -131,6 +131,15 @@ class _VggPyr(object):
             self._handle, C.byref(h), C.byref(w), C.byref(c)), 'dodt_extractor_output_shape')
         return h.value, w.value, c.value
 
+    @property
+    def first_layers_folded(self):
+        """True when conv1_1 runs inside conv1_2's launch (bf16 conv path): its map is not stored, and its products are
+        hi + lo bf16 pairs on the bf16 MFMA (include/dodt_hip.h dodt_extractor_first_layers_folded)."""
+        rc = self._ctx.lib.dodt_extractor_first_layers_folded(self._handle)
+        if rc < 0:
+            _lib.check(rc, 'dodt_extractor_first_layers_folded')
+        return bool(rc)
+
     def flops(self):
         return self._ctx.lib.dodt_extractor_flops(self._handle)
 

@@ -175,11 +175,11 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         static const long mt2_below = getenv("DODT_CONV_BF16_MT2_BELOW") ? atol(getenv("DODT_CONV_BF16_MT2_BELOW")) : 0;
         long n16 = 0;
         for (size_t i = 0; i < vs.size(); ++i)
-            if (vs[i].dma && !vs[i].stream_nch && vs[i].TH == 16 && Cout % vs[i].BN == 0)
+            if (vs[i].dma && !vs[i].stream_nch && !vs[i].first2 && vs[i].TH == 16 && Cout % vs[i].BN == 0)
                 n16 = std::max(n16, (long)dodt::ceil_div(H, 16) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch);
         const bool want_mt2 = mt2 && n16 < (mt2_below > 0 ? mt2_below : 8L * num_cus / 5);
         for (size_t i = 0; i < vs.size(); ++i) {
-            if (!vs[i].dma || vs[i].stream_nch || Cout % vs[i].BN != 0) continue;
+            if (!vs[i].dma || vs[i].stream_nch || vs[i].first2 || Cout % vs[i].BN != 0) continue;
             if ((vs[i].TH == 8) != want_mt2) continue;
             const long n = (long)dodt::ceil_div(H, vs[i].TH) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch;
             const bool enough = n >= per_cu * num_cus, best_enough = best_n >= per_cu * num_cus;
@@ -372,6 +372,7 @@ struct Layer {
     float *d_scale = nullptr, *d_shift = nullptr;
     bool loaded = false;
     int real_cin = 0;  // channels that carry data (conv1_1 of the image net: 3 of 4)
+    float* d_first_w = nullptr;   // conv1_1 of a bf16 extractor: hi + lo bf16 MFMA fragments for conv3x3_bf16_first2_kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // dodt_extractor_forward_timed
 };
 
@@ -396,6 +397,7 @@ struct dodt_extractor {
     bool bneck_loaded = false;
     double flops = 0.0;
     bool timed = false;   // this forward records an event pair around every layer
+    int first2_variant = -1;   // >= 0: conv1_1 runs folded into conv1_2's launch (bf16 conv path; DODT_CONV_BF16_FIRST2=0: not)
     float* own_x0 = nullptr;   // the extractor's own input buffer while dodt_extractor_set_input points X0 elsewhere
 };
 
@@ -410,9 +412,10 @@ int find_layer(dodt_extractor* ex, const char* name) {
 int buffer_for_layer_output(const Layer& l) { return l.dst; }
 
 int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
-               float* override_out, int out_y0, int out_h, float* bneck_out, int pool_dst) {
-    const KernelVariant& v = variants()[ln.variant];
-    const Buffer& src = ex->buf[l.src];
+               float* override_out, int out_y0, int out_h, float* bneck_out, int pool_dst, const Layer* folded = nullptr) {
+    // folded: conv1_1, computed inside this launch of conv1_2 (same items and weights as conv1_2's streaming kernel)
+    const KernelVariant& v = variants()[folded ? ex->first2_variant : ln.variant];
+    const Buffer& src = ex->buf[folded ? folded->src : l.src];
     const Buffer& dst = ex->buf[l.dst];
     ConvArgs a;
     a.in = src.ptr;
@@ -425,7 +428,7 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.Cin = l.Cin;
     a.Cout = l.Cout;
     a.in_ld = src.C;
-    a.in_coff = l.src_coff;
+    a.in_coff = folded ? folded->src_coff : l.src_coff;
     a.out_ld = dst.C;
     a.out_coff = l.dst_coff;
     a.in_frame_stride = (long long)src.frame_floats();
@@ -459,6 +462,9 @@ int run_launch(dodt_extractor* ex, const Layer& l, const Launch& ln, int which,
     a.bneck_shift = ex->bneck_shift;
     a.bneck_frame_stride = (long long)out_h * dst.W;
     a.zeros = ex->d_zeros;
+    a.first_w = folded ? folded->d_first_w : nullptr;
+    a.first_scale = folded ? folded->d_scale : nullptr;
+    a.first_shift = folded ? folded->d_shift : nullptr;
     // persistent workgroups: as many as stay resident, each walks items with that stride
     int grid_x = a.n_items;
     {
@@ -535,9 +541,13 @@ bool layer_can_pool(const Layer& l) {
 
 // pool_dst >= 0: the layer also writes its 2x2 max pool into that buffer
 int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y0, int out_h,
-              float* bneck_out = nullptr, int pool_dst = -1) {
+              float* bneck_out = nullptr, int pool_dst = -1, const Layer* folded = nullptr) {
+    if (ex->timed && folded) {      // (the folded layer has no time of its own)
+        DODT_HIP_CHECK(hipEventRecord(folded->ev0, ex->ctx->stream));
+        DODT_HIP_CHECK(hipEventRecord(folded->ev1, ex->ctx->stream));
+    }
     if (ex->timed) DODT_HIP_CHECK(hipEventRecord(l.ev0, ex->ctx->stream));
-    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h, bneck_out, pool_dst);
+    int rc = run_launch(ex, l, l.main, 0, override_out, out_y0, out_h, bneck_out, pool_dst, folded);
     if (rc == DODT_OK && l.tail.n_items > 0)
         rc = run_launch(ex, l, l.tail, 1, override_out, out_y0, out_h, bneck_out, pool_dst);
     if (rc == DODT_OK && ex->timed) DODT_HIP_CHECK(hipEventRecord(l.ev1, ex->ctx->stream));
@@ -548,6 +558,7 @@ int run_layer(dodt_extractor* ex, const Layer& l, float* override_out, int out_y
 const char* kernel_name(const KernelVariant& v) {
     if (v.wino) return v.wino_m == 4 ? "wino43_f32_kernel" : "wino3x3_f32_kernel";
     if (v.deconv_dma) return "deconv3x3_dma_kernel";
+    if (v.first2) return "conv3x3_bf16_first2_kernel";
     if (v.stream_nch) return "conv3x3_bf16_stream_kernel";
     if (v.dma) return "conv3x3_bf16_dma_kernel";
     if (v.small_cin) return "conv3x3_small_cin_kernel";
@@ -793,7 +804,22 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         }
         DODT_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
     }
+    {
+        // bf16 conv path: conv1_1 folded into conv1_2's launch when conv1_2 runs on the streaming kernel (same tiles, same
+        // weight blocking) and the input rows are whole 16-byte slots (DODT_CONV_BF16_FIRST2=0: two launches)
+        static const bool first2 = !(getenv("DODT_CONV_BF16_FIRST2") && atoi(getenv("DODT_CONV_BF16_FIRST2")) == 0);
+        const Layer& c11 = ex->layers[0];
+        const Layer& c12 = ex->layers[1];
+        const auto& vs = variants();
+        if (first2 && bf16 && ex->parts == 1 && vs[c12.variant].stream_nch == 2 && c12.tail.n_items == 0 &&
+            c11.Cout == 32 && c11.src_coff == 0 && ex->buf[X0].C == c11.Cin && (W * c11.Cin * 4) % 16 == 0 &&
+            variant_can_pool(vs[c12.variant]))
+            for (size_t i = 0; i < vs.size(); ++i)
+                if (vs[i].first2 == c11.Cin && vs[i].TH == vs[c12.variant].TH && vs[i].TW == vs[c12.variant].TW)
+                    ex->first2_variant = (int)i;
+    }
     if (getenv("DODT_DEBUG_PLAN")) {
+        if (ex->first2_variant >= 0) fprintf(stderr, "[dodt] conv1_1 runs folded into conv1_2's launch\n");
         for (const Layer& l : ex->layers) {
             const KernelVariant& v = variants()[l.variant];
             fprintf(stderr, "[dodt] %-16s %4dx%-4d %3d->%-3d TW%d TH%d BN%d CK%d lds %d items %d",
@@ -823,6 +849,7 @@ int dodt_extractor_destroy(dodt_extractor* ex) {
         }
         if (l.d_scale) (void)hipFree(l.d_scale);
         if (l.d_shift) (void)hipFree(l.d_shift);
+        if (l.d_first_w) (void)hipFree(l.d_first_w);
     }
     if (ex->d_bneck_w) (void)hipFree(ex->d_bneck_w);
     for (Layer& l : ex->layers) {
@@ -1010,6 +1037,32 @@ int dodt_extractor_set_layer(dodt_extractor* ex, const char* name, const float* 
                                   hipMemcpyHostToDevice, s));
     DODT_HIP_CHECK(hipStreamSynchronize(s));
     }
+    if (li == 0 && ex->bf16 && ex->parts == 1 && l.Cout == 32 && (l.Cin == 6 || l.Cin == 4)) {
+        // conv1_1 for conv3x3_bf16_first2_kernel: A fragments [K = 16 step][hi, lo][lane half][32 MFMA rows][8 bf16];
+        // a lane half's eight K slots are one tap's six channels + two zeros (Cin 6: taps 2 s + lh) or two taps' four
+        // channels (Cin 4: taps 4 s + 2 lh, + 1); w = hi + lo to 16 mantissa bits
+        const int steps = l.Cin == 6 ? 5 : 3;
+        std::vector<uint16_t> frag((size_t)steps * 2 * 2 * 32 * 8, 0);
+        for (int st = 0; st < steps; ++st)
+            for (int lh = 0; lh < 2; ++lh)
+                for (int row = 0; row < 32; ++row) {
+                    // channel of MFMA row 8 (2 a + b) + 4 lh' + k: 16 a + 8 lh' + 4 b + k (group_channel<true>)
+                    const int g = row >> 3, lho = (row >> 2) & 1, co = 16 * (g >> 1) + 8 * lho + 4 * (g & 1) + (row & 3);
+                    for (int j = 0; j < 8; ++j) {
+                        const int tap = l.Cin == 6 ? 2 * st + lh : 4 * st + 2 * lh + (j >> 2);
+                        const int ci = l.Cin == 6 ? j : (j & 3);
+                        if (tap >= 9 || ci >= cin) continue;
+                        const float val = w[((size_t)tap * cin + ci) * cout + co];
+                        const uint16_t hi = dodt::float_to_bf16(val);
+                        const size_t at = ((((size_t)st * 2 + 0) * 2 + lh) * 32 + row) * 8 + j;
+                        frag[at] = hi;
+                        frag[at + 2 * 32 * 8] = dodt::float_to_bf16(val - dodt::bf16_to_float(hi));
+                    }
+                }
+        if (!l.d_first_w) DODT_HIP_CHECK(hipMalloc(&l.d_first_w, frag.size() * sizeof(uint16_t)));
+        DODT_HIP_CHECK(hipMemcpyAsync(l.d_first_w, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        DODT_HIP_CHECK(hipStreamSynchronize(s));
+    }
     std::vector<float> scale(l.Cout), shift(l.Cout);
     for (int co = 0; co < l.Cout; ++co) {
         const float inv = 1.0f / std::sqrt(var[co] + 0.001f);
@@ -1076,7 +1129,11 @@ int dodt_extractor_forward(dodt_extractor* ex, const float* d_in, float* d_feat_
         for (const char* n : {"conv1_2", "conv2_2", "conv3_3"})
             DODT_REQUIRE(!no_fuse && layer_can_pool(L(n)),
                          "bf16 extractor: layer %s cannot pool in its epilogue", n);
-    RUN("conv1_1"); RUN_POOLED("conv1_2", CAT1, P1);
+    if (ex->first2_variant >= 0) {
+        if ((rc = run_layer(ex, L("conv1_2"), nullptr, 0, 0, nullptr, P1, &L("conv1_1")))) return rc;
+    } else {
+        RUN("conv1_1"); RUN_POOLED("conv1_2", CAT1, P1);
+    }
     RUN("conv2_1"); RUN_POOLED("conv2_2", CAT2, P2);
     RUN("conv3_1"); RUN("conv3_2"); RUN_POOLED("conv3_3", CAT3, P3);
 #undef RUN_POOLED
@@ -1144,12 +1201,19 @@ int dodt_extractor_output_shape(const dodt_extractor* ex, int* h, int* w, int* c
     return DODT_OK;
 }
 
+int dodt_extractor_first_layers_folded(const dodt_extractor* ex) {
+    DODT_REQUIRE(ex, "dodt_extractor_first_layers_folded: extractor is NULL");
+    return ex->first2_variant >= 0 ? 1 : 0;
+}
+
 int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* dst, int* h,
                                    int* w, int* c) {
     DODT_REQUIRE(ex && name, "dodt_extractor_read_activation: NULL argument");
     const int li = find_layer(ex, name);
     DODT_REQUIRE(li >= 0, "dodt_extractor_read_activation: unknown layer '%s'", name);
     const Layer& l = ex->layers[li];
+    DODT_REQUIRE(!(li == 0 && ex->first2_variant >= 0),
+                 "layer %s runs folded into conv1_2's launch: its map is not stored (DODT_CONV_BF16_FIRST2=0 keeps it)", name);
     const Buffer& b = ex->buf[buffer_for_layer_output(l)];
     DODT_REQUIRE(b.ptr != nullptr,
                  "layer %s is written straight into the caller's output buffer", name);

@@ -330,6 +330,101 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
 }
 
 
+// Epilogue of the streaming kernels for one item: batch-norm + ReLU, stores, fused 2x2 pool / 1x1 bottleneck -- what
+// store_tile / pool_tile of conv_kernels.h do for the other kernels, with the per-channel parameters (s_par: scale[32],
+// shift[32], bottleneck weights[32]) read from LDS in one batch (an item is 1-2 us here: eight dependent parameter loads per
+// tile were twice the MFMAs' time) and the pool's horizontal neighbour taken by DPP.
+// MODE 0: CB16 bf16 map, 1: the same + its 2x2 max pool, 2: NHWC fp32 (+ bottleneck).  Returns nothing; `mid` (optional
+// diagnostic) receives s_memtime between the stores and the pool.
+struct StreamTile { int frame, ty0, tx0; };
+template <int MODE, int MT>
+__device__ __forceinline__ void stream_epilogue(const ConvArgs& a, const float* s_par, f32x16 (&acc)[MT], const StreamTile cur,
+                                                int wave, int li, int lh, bool stamp, int* stamps) {
+    const float floor_v = a.relu ? 0.0f : -3.0e38f;
+    {
+        f32x4 sc[4], sh[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = group_channel<true>(g, lh);
+            sc[g] = *reinterpret_cast<const f32x4*>(s_par + c);
+            sh[g] = *reinterpret_cast<const f32x4*>(s_par + 32 + c);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[mt][r] = fmaxf(acc[mt][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], floor_v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int out_rows = a.H - a.out_y0;
+    const long long plane = (long long)out_rows * a.W * 8;
+    float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
+    const int x = cur.tx0 + li;
+    f32x4 bw[4];      // (read when the scales are dead: the 64-channel instance has 144 registers of weights)
+    if (MODE == 2 && a.bneck_w) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[g] = *reinterpret_cast<const f32x4*>(s_par + 64 + group_channel<true>(g, lh));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int y = cur.ty0 + wave * MT + mt;
+        const bool ok = y < a.H && x < a.W && y >= a.out_y0 && !(a.debug & 1);      // (tools/: 1 = no stores)
+        const size_t px = (size_t)(y - a.out_y0) * a.W + x;
+        if (MODE == 2) {
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(out + px * a.out_ld + a.out_coff + group_channel<true>(g, lh)) =
+                        f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+            }
+            if (a.bneck_w) {
+                float dot = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot += acc[mt][r] * bw[r >> 2][r & 3];
+                dot += __shfl_xor(dot, 32, 64);          // the other 16 channels of this pixel live in lane ^ 32
+                if (ok && lh == 0)
+                    a.bneck_out[(size_t)cur.frame * a.bneck_frame_stride + px] =
+                        fmaxf(dot * a.bneck_scale + a.bneck_shift, 0.0f);
+            }
+        } else if (ok) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)       // groups (2 gp, 2 gp + 1): 8 consecutive channels = one 16-byte store
+                *reinterpret_cast<f32x4*>(out + (size_t)((a.out_coff + 16 * gp) >> 4) * plane + px * 8 + 4 * lh) =
+                    f32x4{pack_bf16(acc[mt][8 * gp], acc[mt][8 * gp + 1]), pack_bf16(acc[mt][8 * gp + 2], acc[mt][8 * gp + 3]),
+                          pack_bf16(acc[mt][8 * gp + 4], acc[mt][8 * gp + 5]), pack_bf16(acc[mt][8 * gp + 6], acc[mt][8 * gp + 7])};
+        }
+    }
+    if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+    if (MODE == 1) {
+        // VALID 2x2 pool of the activated rows (mt, mt + 1): vertical neighbour = the same lane of the next row,
+        // horizontal = lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes at even (y, x) store
+        const int OW = a.W >> 1;
+        const long long pplane = (long long)(a.H >> 1) * OW * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt += 2) {
+            const int y = cur.ty0 + wave * MT + mt;
+            const bool writer = y < a.H && x < a.W && !(y & 1) && !(x & 1) && y + 1 < a.H && x + 1 < a.W && !(a.debug & 1);
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = fmaxf(acc[mt][r], acc[mt + 1][r]);
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                    0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
+                m[r] = fmaxf(t, o);
+            }
+            if (writer) {
+                float* base = a.pool_out + (size_t)cur.frame * a.pool_frame_stride +
+                              ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp)
+                    *reinterpret_cast<f32x4*>(base + (size_t)gp * pplane) =
+                        f32x4{pack_bf16(m[8 * gp], m[8 * gp + 1]), pack_bf16(m[8 * gp + 2], m[8 * gp + 3]),
+                              pack_bf16(m[8 * gp + 4], m[8 * gp + 5]), pack_bf16(m[8 * gp + 6], m[8 * gp + 7])};
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Round 4, late: the level-1 layers (32 output channels, 32 or 64 input channels: conv1_2, pyramid_fusion1 -- 0.25 of
 // the bf16 stacks' time) are HBM-bound at ~3 TB/s with the kernel above: it has ONE 20 KB chunk per workgroup on its
@@ -571,101 +666,362 @@ conv3x3_bf16_stream_kernel(const ConvArgs a) {
         // the asm MFMAs are opaque to the hazard recogniser: 16-pass results need 18 wait states
 #pragma unroll
         for (int k = 0; k < MT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
-        // ---- epilogue: batch-norm + ReLU, stores, fused 2x2 pool / 1x1 bottleneck -- what store_tile / pool_tile of
-        // conv_kernels.h do for the other kernels, with the per-channel parameters read from LDS in one batch (an item is
-        // 1-2 us here: eight dependent parameter loads per tile were twice the MFMAs' time) and the pool's horizontal
-        // neighbour taken by DPP
         const Item cur = decode(item);
-        auto epilogue = [&](auto mode_c) {
-            constexpr int MODE = decltype(mode_c)::value;     // 0: CB16 bf16 map, 1: the same + its 2x2 max pool, 2: NHWC fp32 (+ bottleneck)
-            const float floor_v = a.relu ? 0.0f : -3.0e38f;
-            {
-                f32x4 sc[4], sh[4];
+        const StreamTile cur_t{cur.frame, cur.ty0, cur.tx0};
+        if (a.pool_out) stream_epilogue<1, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
+        else if (!a.out_nhwc) stream_epilogue<0, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
+        else stream_epilogue<2, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
+        if (stamp) { stamps[4] = (int)__builtin_amdgcn_s_memtime(); stamps[5] = stamps[4]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv1_1 folded into conv1_2 (bf16 conv path): one launch reads the net's NHWC fp32 input and writes conv1_2's map and its
+// 2x2 pool; conv1_1's map (72 MB per BEV pair written and read back, a third of the two layers' traffic) never leaves the CU.
+// The structure is conv3x3_bf16_stream_kernel's -- wave 3 streams raw input patches (a ring of S, 10 x 36 pixels each) by
+// LDS-DMA, waves 0-2 compute, the grouped ticket queue feeds both -- with two phases per item:
+//   A. conv1_1 on the 8 x 34 pixels conv1_2's tile needs (272 = 8.5 MFMA tiles of 32, three per wave) on the bf16 MFMA at
+//      fp32 grade: x and w as hi + lo bf16 pairs (v = hi + lo to 16 mantissa bits), a product is
+//      w_hi x_hi + w_lo x_hi + w_hi x_lo in three MFMAs (what the split mode of DESIGN.md 5a' does for every layer; the
+//      dropped terms are 2^-17 of a product, the map is rounded to bf16 = 2^-9 behind it).  On the fp32 MFMA the same
+//      phase is 27 x 64 cycles per tile against 15 x 32: measured, it made the folded launch as slow as the two launches.
+//      The PRODUCER wave, idle between its copies, splits every raw patch once, while the consumers are in phase B of the
+//      item before: pixel records [hi: the pixel's channels, zero-padded to 16 (CIN0 = 6) or 8 bytes | lo: the same], two
+//      buffers by item parity.  A consumer lane's B operands of a K = 16 step are then one or two 16-byte LDS reads
+//      (CIN0 = 6: one tap's record per lane half, five steps; CIN0 = 4: two taps' per lane half, three steps; taps beyond
+//      the ninth read a zero record) -- splitting in the consumers, per tap, was 2.5x the MFMAs' time in VALU work.
+//      Batch-norm + ReLU, zero outside the image (conv1_2's SAME padding), round to bf16, two 16-byte LDS writes per lane
+//      and tile into the two chunk images conv1_2 reads -- the same swizzled layout the DMA kernels stage from memory.
+//   B. conv1_2 from those images (both chunks resident: 36 MFMAs back to back), epilogue with the fused pool.
+// Two barriers per item: X (raw patch n landed, phase B of n - 1 over) and Y (phase A of n written).
+template <int CIN0, int S>
+struct Bf16First2Cfg {
+    static constexpr int MT = 2, TW = 32, TH = 3 * MT, BN = 32;
+    static constexpr int PH = TH + 2, PW = TW + 2;                  // conv1_2's input patch = conv1_1's output tile
+    static constexpr int RH = TH + 4, RW = TW + 4;                  // the raw input patch
+    static constexpr int kPixBytes = CIN0 * 4;
+    static constexpr int kRowSlots = RW * kPixBytes / 16;           // 16-byte slots per raw patch row
+    static constexpr int kRawSlots = RH * kRowSlots;
+    static constexpr int kCopies = (kRawSlots + 63) / 64;
+    static constexpr int kRawFloats = kCopies * 256;
+    static constexpr int kImgFloats = ((PH * PW * 2 + 63) / 64) * 256;     // a chunk image, as in the other kernels
+    static constexpr int kSteps = CIN0 == 6 ? 5 : 3;                // K = 16 steps of phase A
+    static constexpr int kWFloats = 9 * 2 * BN * 4;                 // conv1_2: a chunk's weights in global memory
+    static constexpr int kRecFloats = CIN0 == 6 ? 8 : 4;           // a split pixel record: hi | lo
+    static constexpr int kSplitFloats = (RH * RW + 1) * kRecFloats; // ... of every raw pixel, and a zero record
+    static constexpr int kLdsBytes = (S * kRawFloats + 2 * kSplitFloats + 2 * kImgFloats) * 4 + 64 + 4 * 32 * 4;   // | item ring | scale, shift x 2
+    static_assert(CIN0 == 6 || CIN0 == 4, "BEV maps (6) or the padded image (4)");
+    static_assert((RW * kPixBytes) % 16 == 0, "whole slots per row");
+    static_assert((S - 2) * kCopies <= 63, "vmcnt is six bits");
+    static_assert(S + 2 <= 16, "item ring");
+};
+
+template <int CIN0, int S>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_bf16_first2_kernel(const ConvArgs a) {
+    using Cfg = Bf16First2Cfg<CIN0, S>;
+    constexpr int MT = Cfg::MT, BN = Cfg::BN, PW = Cfg::PW, RW = Cfg::RW, KC = Cfg::kCopies, NS = Cfg::kSteps;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_split = smem + S * Cfg::kRawFloats;                      // split raw patches, by item parity
+    float* s_img = s_split + 2 * Cfg::kSplitFloats;                   // conv1_2's two chunk images
+    int* s_q = reinterpret_cast<int*>(s_img + 2 * Cfg::kImgFloats);   // item ring
+    float* s_par = reinterpret_cast<float*>(s_q + 16);                // conv1_2: scale[32], shift[32]; then conv1_1's
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the producer is wave 3 in the first workgroup of a CU and wave 2 in the second (blocks b and b + CUs share a CU when
+    // the grid is two per CU): the consumers' MFMAs then spread over all four SIMDs
+    const int producer_wave = 3 - (int)((blockIdx.x / ((gridDim.x + 1) / 2)) & 1);
+    const bool producer = wave == producer_wave;
+    const int cw = wave < producer_wave ? wave : wave - 1;            // consumer index 0..2
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    auto decode = [&](int it) {
+        it = __builtin_amdgcn_readfirstlane(it);
+        const int f = it / tiles_per_frame, r = it - f * tiles_per_frame;
+        const int ty = r / a.tiles_x;
+        return StreamTile{f, ty * Cfg::TH, (r - ty * a.tiles_x) * Cfg::TW};
+    };
+    const bool grouped = a.xcd_counters != nullptr;
+    const int vx = grouped ? (int)(blockIdx.x & 7) : 0;
+    const int q_lo = grouped ? vx * (a.n_items / 8) + min(vx, a.n_items % 8) : 0;
+    const int q_hi = grouped ? q_lo + a.n_items / 8 + (vx < a.n_items % 8 ? 1 : 0) : a.n_items;
+    const int q_blocks = grouped ? ((int)gridDim.x - vx + 7) / 8 : (int)gridDim.x;
+    const int q_first = q_lo + q_blocks;
+    int* const q_counter = grouped ? a.xcd_counters + 16 * vx : a.counter;
+    auto ticket_item = [&](int t) { return q_first + t < q_hi ? q_first + t : a.n_items; };
+    const int k_first = q_lo + (grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    if (k_first >= q_hi) return;
+    if (tid < 128)
+        s_par[tid] = tid < 32 ? a.scale[tid] : tid < 64 ? a.shift[tid - 32]
+                   : tid < 96 ? a.first_scale[tid - 64] : a.first_shift[tid - 96];
+    auto queue_at = [&](int n) { return __builtin_amdgcn_readfirstlane(s_q[n & 15]); };
+    // ring entries 0 .. S of this workgroup (the producer sets up item n + S at the top of item n); item n publishes entry
+    // n + S + 1 with the ticket drawn an item before (the first of them here)
+    int ticket = 0;
+    if (tid == 0) {
+        s_q[0] = k_first;
+        const int t = atomicAdd(q_counter, S + 1);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = group_channel<true>(g, lh);
-                    sc[g] = *reinterpret_cast<const f32x4*>(s_par + c);
-                    sh[g] = *reinterpret_cast<const f32x4*>(s_par + 32 + c);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[mt][r] = fmaxf(acc[mt][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], floor_v);
+        for (int i = 0; i < S; ++i) s_q[1 + i] = ticket_item(t + i);
+        ticket = t + S;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+
+    if (producer) {
+        int p_off[KC];
+        i32x4_t in_rsrc;
+        const int row_bytes = a.W * Cfg::kPixBytes;
+        auto setup = [&](int item) {
+            if (item >= a.n_items) {
+                in_rsrc = make_rsrc(a.in, 0u);
+                return;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const int out_rows = a.H - a.out_y0;
-            const long long plane = (long long)out_rows * a.W * 8;
-            float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
-            const int x = cur.tx0 + li;
-            f32x4 bw[4];      // (read when the scales are dead: the 64-channel instance has 144 registers of weights)
-            if (MODE == 2 && a.bneck_w) {
+            const StreamTile it = decode(item);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bw[g] = *reinterpret_cast<const f32x4*>(s_par + 64 + group_channel<true>(g, lh));
+            for (int k = 0; k < KC; ++k) {
+                const int s = k * 64 + lane;
+                const int r = s / Cfg::kRowSlots, j = s - r * Cfg::kRowSlots;
+                const int gy = it.ty0 - 2 + r;
+                const int xb = (it.tx0 - 2) * Cfg::kPixBytes + 16 * j;       // byte in the image row: whole slots in or out
+                const bool ok = r < Cfg::RH && gy >= 0 && gy < a.H && xb >= 0 && xb < row_bytes;
+                p_off[k] = ok ? gy * row_bytes + xb : kOob;
             }
+            in_rsrc = make_rsrc(a.in + (size_t)it.frame * a.in_frame_stride,
+                                (a.debug & 2) ? 0u : (unsigned)(a.H * row_bytes));
+        };
+        int c_n = 0, c_slot = 0;
+        auto copies = [&]() {
+            const unsigned img = lds0 + (unsigned)(c_slot * Cfg::kRawFloats) * 4;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int y = cur.ty0 + wave * MT + mt;
-                const bool ok = y < a.H && x < a.W && y >= a.out_y0 && !(a.debug & 1);      // (tools/: 1 = no stores)
-                const size_t px = (size_t)(y - a.out_y0) * a.W + x;
-                if (MODE == 2) {
-                    if (ok) {
+            for (int k = 0; k < KC; ++k) blds16s(in_rsrc, p_off[k], 0, img + k * 1024);
+            c_slot = c_slot + 1 == S ? 0 : c_slot + 1;
+            ++c_n;
+            setup(queue_at(c_n));        // (the entry was published at least a barrier ago)
+        };
+        // raw patch m (ring slot m % S) -> hi | lo records in split buffer m & 1
+        auto split_patch = [&](int m_slot, int par) {
+            const float* raw = smem + m_slot * Cfg::kRawFloats;
+            float* dst = s_split + par * Cfg::kSplitFloats;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<f32x4*>(out + px * a.out_ld + a.out_coff + group_channel<true>(g, lh)) =
-                                f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                    }
-                    if (a.bneck_w) {
-                        float dot = 0.0f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dot += acc[mt][r] * bw[r >> 2][r & 3];
-                        dot += __shfl_xor(dot, 32, 64);          // the other 16 channels of this pixel live in lane ^ 32
-                        if (ok && lh == 0)
-                            a.bneck_out[(size_t)cur.frame * a.bneck_frame_stride + px] =
-                                fmaxf(dot * a.bneck_scale + a.bneck_shift, 0.0f);
-                    }
-                } else if (ok) {
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp)       // groups (2 gp, 2 gp + 1): 8 consecutive channels = one 16-byte store
-                        *reinterpret_cast<f32x4*>(out + (size_t)((a.out_coff + 16 * gp) >> 4) * plane + px * 8 + 4 * lh) =
-                            f32x4{pack_bf16(acc[mt][8 * gp], acc[mt][8 * gp + 1]), pack_bf16(acc[mt][8 * gp + 2], acc[mt][8 * gp + 3]),
-                                  pack_bf16(acc[mt][8 * gp + 4], acc[mt][8 * gp + 5]), pack_bf16(acc[mt][8 * gp + 6], acc[mt][8 * gp + 7])};
-                }
-            }
-            if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
-            if (MODE == 1) {
-                // VALID 2x2 pool of the activated rows (mt, mt + 1): vertical neighbour = the same lane of the next row,
-                // horizontal = lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes at even (y, x) store
-                const int OW = a.W >> 1;
-                const long long pplane = (long long)(a.H >> 1) * OW * 8;
-#pragma unroll
-                for (int mt = 0; mt < MT; mt += 2) {
-                    const int y = cur.ty0 + wave * MT + mt;
-                    const bool writer = y < a.H && x < a.W && !(y & 1) && !(x & 1) && y + 1 < a.H && x + 1 < a.W && !(a.debug & 1);
-                    float m[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float t = fmaxf(acc[mt][r], acc[mt + 1][r]);
-                        const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                            0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
-                        m[r] = fmaxf(t, o);
-                    }
-                    if (writer) {
-                        float* base = a.pool_out + (size_t)cur.frame * a.pool_frame_stride +
-                                      ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
-#pragma unroll
-                        for (int gp = 0; gp < 2; ++gp)
-                            *reinterpret_cast<f32x4*>(base + (size_t)gp * pplane) =
-                                f32x4{pack_bf16(m[8 * gp], m[8 * gp + 1]), pack_bf16(m[8 * gp + 2], m[8 * gp + 3]),
-                                      pack_bf16(m[8 * gp + 4], m[8 * gp + 5]), pack_bf16(m[8 * gp + 6], m[8 * gp + 7])};
+            for (int k = 0; k < (Cfg::RH * Cfg::RW + 63) / 64; ++k) {
+                const int q = k * 64 + lane;
+                if (q < Cfg::RH * Cfg::RW) {
+                    if constexpr (CIN0 == 6) {
+                        const f32x2 v0 = *reinterpret_cast<const f32x2*>(raw + q * 6),
+                                    v1 = *reinterpret_cast<const f32x2*>(raw + q * 6 + 2),
+                                    v2 = *reinterpret_cast<const f32x2*>(raw + q * 6 + 4);
+                        const float h0 = pack_bf16(v0[0], v0[1]), h1 = pack_bf16(v1[0], v1[1]), h2 = pack_bf16(v2[0], v2[1]);
+                        *reinterpret_cast<f32x4*>(dst + q * 8) = f32x4{h0, h1, h2, 0.f};
+                        *reinterpret_cast<f32x4*>(dst + q * 8 + 4) =
+                            f32x4{pack_bf16(v0[0] - bf16_value(h0, 0), v0[1] - bf16_value(h0, 1)),
+                                  pack_bf16(v1[0] - bf16_value(h1, 0), v1[1] - bf16_value(h1, 1)),
+                                  pack_bf16(v2[0] - bf16_value(h2, 0), v2[1] - bf16_value(h2, 1)), 0.f};
+                    } else {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(raw + q * 4);
+                        const float h0 = pack_bf16(v[0], v[1]), h1 = pack_bf16(v[2], v[3]);
+                        *reinterpret_cast<f32x4*>(dst + q * 4) =
+                            f32x4{h0, h1, pack_bf16(v[0] - bf16_value(h0, 0), v[1] - bf16_value(h0, 1)),
+                                  pack_bf16(v[2] - bf16_value(h1, 0), v[3] - bf16_value(h1, 1))};
                     }
                 }
             }
         };
-        if (a.pool_out) epilogue(std::integral_constant<int, 1>{});
-        else if (!a.out_nhwc) epilogue(std::integral_constant<int, 0>{});
-        else epilogue(std::integral_constant<int, 2>{});
+        if (lane < 2 * Cfg::kRecFloats)      // the zero records of both buffers
+            s_split[(lane / Cfg::kRecFloats) * Cfg::kSplitFloats + Cfg::RH * Cfg::RW * Cfg::kRecFloats + lane % Cfg::kRecFloats] = 0.f;
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_barrier" ::: "memory");             // B0: the item ring is visible
+        setup(k_first);
+#pragma unroll 1
+        for (int b = 0; b < S - 1; ++b) copies();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * KC) : "memory");      // patch 0 has landed
+        split_patch(0, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("s_barrier" ::: "memory");             // X_0
+        int r_slot = 0;
+        for (int n = 0; queue_at(n) < a.n_items; ++n) {
+            copies();                                        // patch n + S - 1 into the image whose split is long done
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * KC) : "memory");      // patch n + 1 has landed
+            asm volatile("s_barrier" ::: "memory");         // Y_n: phase A of item n is over (split buffer (n + 1) & 1 is free)
+            r_slot = r_slot + 1 == S ? 0 : r_slot + 1;
+            split_patch(r_slot, (n + 1) & 1);                // under phase B and the epilogue of item n
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("s_barrier" ::: "memory");         // X_{n+1}
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- waves 0-2 ------------------------------------------------------------------------------------------
+    // conv1_2's weights (two chunks) and conv1_1's hi / lo fragments: registers
+    f32x4 wreg[2 * 9], w1[NS][2];
+    {
+        const float* wl = a.w + (lh * BN + li) * 4;
+#pragma unroll
+        for (int i = 0; i < 18; ++i)
+            wreg[i] = *reinterpret_cast<const f32x4*>(wl + (size_t)(i / 9) * Cfg::kWFloats + (i % 9) * 2 * BN * 4);
+        // [step][hi, lo][lane half][32 MFMA rows][8 bf16]
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                w1[s][part] = *reinterpret_cast<const f32x4*>(a.first_w + (((s * 2 + part) * 2 + lh) * 32 + li) * 4);
+    }
+    // phase A lane constants: the wave's three MFMA tiles cover patch pixels p = 32 t + li, t = 3 wave + i
+    int a_raw[3], a_cell[3], a_rc[3];       // (a_rc: patch row << 8 | column)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = 32 * (3 * cw + i) + li;
+        const int pq = p < Cfg::PH * PW ? p : Cfg::PH * PW - 1;            // (the last tile is half empty: reads stay inside)
+        const int pr = pq / PW, pc = pq - pr * PW;
+        a_raw[i] = (pr * RW + pc) * Cfg::kRecFloats;                       // floats: the record of tap (0, 0)
+        a_cell[i] = p < Cfg::PH * PW ? (pr * PW + pc) * 8 + ((lh ^ ((pc >> 3) & 1)) * 4) : -1;
+        a_rc[i] = pr << 8 | pc;
+    }
+    // this lane half's tap(s) of step s: float offset of its record from tap (0, 0)'s, or -1 (beyond the ninth tap)
+    auto tap_offset = [&](int s, int u) {
+        auto of = [](int tap) { return tap < 9 ? ((tap / 3) * RW + tap % 3) * Cfg::kRecFloats : -1; };
+        const int t0 = CIN0 == 6 ? 2 * s : 4 * s + u, t1 = CIN0 == 6 ? 2 * s + 1 : 4 * s + 2 + u;     // lane half 0 / 1
+        return lh ? of(t1) : of(t0);
+    };
+    int col_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int c = li + kx;
+        col_off[kx] = c * 8 + ((lh ^ ((c >> 3) & 1)) * 4);
+    }
+    const int row0 = cw * MT * PW * 8;
+    auto mfma_acc = [&](const f32x4& w, const f32x4& x, f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
+    };
+    auto mfma_first = [&](const f32x4& w, const f32x4& x, f32x16& c) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(w), "v"(x));
+    };
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(wreg[i]));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(w1[s][0]), "+v"(w1[s][1]));
+    asm volatile("s_barrier" ::: "memory");                 // B0
+    asm volatile("s_barrier" ::: "memory");                 // X_0: raw patch 0 is in image 0
+    int slot = 0;
+    for (int n = 0;; ++n) {
+        const int item = queue_at(n);
+        if (item >= a.n_items) break;
+        const bool stamp = (a.debug & 32) && blockIdx.x == 1 && tid == 0 && n < 12;
+        int* stamps = a.counter_base + 32 + (n < 12 ? n : 0) * 6;
+        if (stamp) stamps[0] = (int)__builtin_amdgcn_s_memtime();
+        const StreamTile cur = decode(item);
+        // ---- phase A: conv1_1 of the wave's three tiles ----
+        const float* rec = s_split + (n & 1) * Cfg::kSplitFloats;
+        {
+            // (compiler-visible MFMAs here, not the inline-asm ones of phase B: the operands are assembled in registers, and
+            //  only the compiler's hazard recogniser keeps a VALU write away from a register an MFMA in flight still reads)
+            f32x16 c1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c1[i][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                // (a tap beyond the ninth: the zero record behind the patch's; the three tiles' accumulators take turns)
+                f32x4 xh[3], xl[3];
+                if constexpr (CIN0 == 6) {
+                    const int off = tap_offset(s, 0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float* q = rec + (off < 0 ? Cfg::RH * RW * 8 : a_raw[i] + off);
+                        xh[i] = *reinterpret_cast<const f32x4*>(q);
+                        xl[i] = *reinterpret_cast<const f32x4*>(q + 4);
+                    }
+                } else {
+                    const int o0 = tap_offset(s, 0), o1 = tap_offset(s, 1);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rec + (o0 < 0 ? Cfg::RH * RW * 4 : a_raw[i] + o0));
+                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rec + (o1 < 0 ? Cfg::RH * RW * 4 : a_raw[i] + o1));
+                        xh[i] = f32x4{r0[0], r0[1], r1[0], r1[1]};
+                        xl[i] = f32x4{r0[2], r0[3], r1[2], r1[3]};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) c1[i] = mfma_bf16(w1[s][0], xh[i], c1[i]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) c1[i] = mfma_bf16(w1[s][1], xh[i], c1[i]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) c1[i] = mfma_bf16(w1[s][0], xl[i], c1[i]);
+            }
+            // batch-norm + ReLU, zero outside the image, bf16, into the chunk images
+            f32x4 sc[4], sh[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = group_channel<true>(g, lh);
+                sc[g] = *reinterpret_cast<const f32x4*>(s_par + 64 + c);
+                sh[g] = *reinterpret_cast<const f32x4*>(s_par + 96 + c);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int gy = cur.ty0 - 1 + (a_rc[i] >> 8), gx = cur.tx0 - 1 + (a_rc[i] & 255);
+                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                float r[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float v = fmaxf(c1[i][k] * sc[k >> 2][k & 3] + sh[k >> 2][k & 3], 0.0f);
+                    r[k] = inside ? v : 0.0f;
+                }
+                if (a_cell[i] >= 0) {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        *reinterpret_cast<f32x4*>(s_img + ch * Cfg::kImgFloats + a_cell[i]) =
+                            f32x4{pack_bf16(r[8 * ch], r[8 * ch + 1]), pack_bf16(r[8 * ch + 2], r[8 * ch + 3]),
+                                  pack_bf16(r[8 * ch + 4], r[8 * ch + 5]), pack_bf16(r[8 * ch + 6], r[8 * ch + 7])};
+                }
+            }
+        }
+        // queue tickets as in conv3x3_bf16_stream_kernel: publish the one drawn an item ago, draw the next (here, behind
+        // phase A: the wait for the old ticket also waits for the previous epilogue's stores)
+        if (tid == 0) {
+            s_q[(n + S + 1) & 15] = ticket_item(ticket);
+            ticket = atomicAdd(q_counter, 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the images are written, the ring entry too
+        asm volatile("s_barrier" ::: "memory");   // Y_n
+        if (stamp) stamps[1] = (int)__builtin_amdgcn_s_memtime();
+        // ---- phase B: conv1_2, both chunks ----
+        f32x16 acc[MT];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float* sP = s_img + ch * Cfg::kImgFloats + row0;
+            f32x4 x[MT + 2];
+#pragma unroll
+            for (int r = 0; r < MT + 2; ++r) x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g9 = 0; g9 < 9; ++g9) {
+                const int kx = g9 / 3, ky = g9 % 3;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (ch == 0 && g9 == 0) mfma_first(wreg[ky * 3 + kx], x[mt + ky], acc[mt]);
+                    else mfma_acc(wreg[ch * 9 + ky * 3 + kx], x[mt + ky], acc[mt]);
+                }
+                if (ky == 2 && kx < 2) {
+#pragma unroll
+                    for (int r = 0; r < MT + 2; ++r)
+                        x[r] = *reinterpret_cast<const f32x4*>(sP + r * PW * 8 + col_off[kx + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
+        if (stamp) stamps[2] = (int)__builtin_amdgcn_s_memtime();
+        if (a.pool_out) stream_epilogue<1, MT>(a, s_par, acc, cur, cw, li, lh, stamp, stamps);
+        else stream_epilogue<0, MT>(a, s_par, acc, cur, cw, li, lh, stamp, stamps);
         if (stamp) { stamps[4] = (int)__builtin_amdgcn_s_memtime(); stamps[5] = stamps[4]; }
+        slot = slot + 1 == S ? 0 : slot + 1;
+        asm volatile("s_barrier" ::: "memory");   // X_{n+1}
     }
 }
 

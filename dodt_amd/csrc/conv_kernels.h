@@ -89,6 +89,11 @@ struct ConvArgs {
     // tile next to each other, so that a tile's input patch is fetched over the fabric once and is an L2 hit for
     // the other channel tiles.
     int* xcd_counters;
+    // conv3x3_bf16_first2_kernel (conv1_1 folded into conv1_2): `in` is the net's NHWC fp32 input; the first layer's weights
+    // as hi + lo bf16 MFMA fragments (conv.hip dodt_extractor_set_layer) and its batch-norm scale / shift
+    const float* first_w;
+    const float* first_scale;
+    const float* first_shift;
 };
 
 constexpr int kCK = 8;          // input channels per K chunk = one CB8 plane

@@ -25,6 +25,7 @@ struct KernelVariant {
     bool dma = false;        // bf16 kernel with LDS-DMA staging (conv_bf16_dma.h)
     int wino_m = 2;          // Winograd output block: F(2x2,3x3) or F(4x4,3x3) (wino43_kernel.h)
     bool deconv_dma = false; // transposed conv, LDS-DMA staged (deconv_kernel.h)
+    int first2 = 0;          // 6 / 4: conv1_1 (that many input channels) folded into conv1_2 (conv3x3_bf16_first2_kernel)
     int stream_nch = 0;      // > 0: bf16 LDS-DMA kernel with a producer wave and the weights in registers
                              // (conv3x3_bf16_stream_kernel): exactly this many 16-channel chunks, 32 output channels
 };
@@ -156,6 +157,26 @@ struct InstBf16Stream {
         v.bf16 = true;
         v.dma = true;
         v.stream_nch = NCH;
+        return v;
+    }
+};
+
+template <int CIN0, int S>
+struct InstBf16First2 {
+    using Cfg = Bf16First2Cfg<CIN0, S>;
+    static_assert(2 * Cfg::kLdsBytes <= 160 * 1024, "two workgroups per CU");
+    static void launch(const ConvArgs& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL((conv3x3_bf16_first2_kernel<CIN0, S>), grid, dim3(256), Cfg::kLdsBytes, s, a);
+    }
+    static hipError_t prepare() {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_first2_kernel<CIN0, S>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLdsBytes);
+    }
+    static KernelVariant variant() {
+        KernelVariant v{Cfg::TW, Cfg::TH, 3, 1, Cfg::BN, 16, false, false, Cfg::TH, Cfg::kLdsBytes, 2, &launch, &prepare};
+        v.bf16 = true;
+        v.dma = true;
+        v.first2 = CIN0;
         return v;
     }
 };

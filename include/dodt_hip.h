@@ -260,6 +260,11 @@ int dodt_extractor_set_input(dodt_extractor* ex, const float* d_x0);
 /* Size of the feature map forward() returns: (in_h, in_w, 32) for the pyramid,
  * (in_h / 8 * 4, in_w / 8 * 4, 256) for DODT_EXTRACTOR_VGG. */
 int dodt_extractor_output_shape(const dodt_extractor* ex, int* h, int* w, int* c);
+/* 1 when conv1_1 runs folded into conv1_2's launch (bf16 conv path, the default there; bev_vgg_pyramid.py:63-66's two convs in
+ * one kernel): conv1_1's map is then not stored (dodt_extractor_read_activation refuses it) and its arithmetic is the bf16
+ * MFMA's at fp32 grade (x and w as hi + lo bf16 pairs, three MFMAs per product term) instead of the fp32 MFMA's.  0 otherwise
+ * (fp32 / split conv paths, or DODT_CONV_BF16_FIRST2=0); a negative DODT_ERR_* code for a NULL extractor. */
+int dodt_extractor_first_layers_folded(const dodt_extractor* ex);
 /* Debug/test access to an intermediate activation by layer name: copies the
  * (batch, h, w, c) float32 tensor to host memory `dst` (NULL to query shape). */
 int dodt_extractor_read_activation(dodt_extractor* ex, const char* name, float* dst,

@@ -29,11 +29,21 @@ def pyramid_layer_names():
     return names
 
 
-def _cbr(x, p, bf16=False, first=False, last=False):
+def _cbr(x, p, bf16=False, first=False, last=False, first_layer='fp32'):
     """conv + BN + ReLU.  bf16: the device's bf16 conv path (include/dodt_hip.h
     DODT_EXTRACTOR_BF16): weights rounded to bf16 (the input already is, except for the
     first layer, whose arithmetic stays fp32), fp32 accumulation and BN/ReLU, output rounded
-    to bf16 unless it is the network output."""
+    to bf16 unless it is the network output.
+    first_layer 'split' (with bf16): the first layer as the device computes it when it folds
+    conv1_1 into conv1_2's launch (dodt_extractor_first_layers_folded): x and w as hi + lo bf16
+    pairs (hi = bf16(v), lo = bf16(v - hi)), w_hi x_hi + w_lo x_hi + w_hi x_lo summed in fp32."""
+    if bf16 and first and first_layer == 'split':
+        xh = tfops.round_bf16(x)
+        xl = tfops.round_bf16(x - xh)
+        wh = tfops.round_bf16(p['w'])
+        wl = tfops.round_bf16(p['w'] - wh)
+        conv = tfops.conv2d_same(xh, wh) + tfops.conv2d_same(xh, wl) + tfops.conv2d_same(xl, wh)
+        return tfops.round_bf16(tfops.bn_relu(conv, p['beta'], p['mean'], p['var']))
     w = p['w'] if (not bf16 or first) else tfops.round_bf16(p['w'])
     y = tfops.bn_relu(tfops.conv2d_same(x, w), p['beta'], p['mean'], p['var'])
     return tfops.round_bf16(y) if (bf16 and not last) else y
@@ -45,7 +55,7 @@ def _ubr(x, p, bf16=False):
     return tfops.round_bf16(y) if bf16 else y
 
 
-def encoder(x, params, collect=None, bf16=False):
+def encoder(x, params, collect=None, bf16=False, first_layer='fp32'):
     """Returns [conv1, conv2, conv3, conv4] block outputs (pre-pool)."""
     outs = []
     for bi, (block, reps) in enumerate(ENCODER):
@@ -53,22 +63,23 @@ def encoder(x, params, collect=None, bf16=False):
             x = tfops.max_pool_2x2(x)
         for r in range(reps):
             name = '%s_%d' % (block, r + 1)
-            x = _cbr(x, params[name], bf16, first=(name == 'conv1_1'))
+            x = _cbr(x, params[name], bf16, first=(name == 'conv1_1'), first_layer=first_layer)
             if collect is not None:
                 collect[name] = x
         outs.append(x)
     return outs
 
 
-def vgg_pyramid(x, params, pad_top=0, collect=None, conv_dtype='f32'):
+def vgg_pyramid(x, params, pad_top=0, collect=None, conv_dtype='f32', first_layer='fp32'):
     """x (H,W,C) float32 -> (H,W,32) full-resolution pyramid feature map.
-    conv_dtype 'bf16' restates the device's bf16 conv path (see _cbr)."""
+    conv_dtype 'bf16' restates the device's bf16 conv path, first_layer its first layer's
+    arithmetic (see _cbr)."""
     bf16 = conv_dtype == 'bf16'
     x = np.asarray(x, dtype=np.float32)
     if pad_top:
         x = np.concatenate(
             [np.zeros((pad_top,) + x.shape[1:], dtype=np.float32), x], axis=0)
-    c1, c2, c3, c4 = encoder(x, params, collect, bf16)
+    c1, c2, c3, c4 = encoder(x, params, collect, bf16, first_layer)
     up3 = _ubr(c4, params['upconv3'], bf16)
     f3 = _cbr(np.concatenate([c3, up3], axis=2), params['pyramid_fusion3'], bf16)
     up2 = _ubr(f3, params['upconv2'], bf16)

@@ -32,11 +32,19 @@ def _run(cls, x, params, pad_top):
     ex = cls(conv_dtype='bf16')
     ex.load_params(params)
     feat, ends = ex.build(x, with_bottleneck=True)
+    # conv1_1 runs folded into conv1_2's launch by default (conv3x3_bf16_first2_kernel): its map is not stored -- conv1_2's
+    # bars check it --, and its products are hi + lo bf16 pairs, which the oracle restates (first_layer='split');
+    # test_two_launch_first_layers_match_the_same_bars stores conv1_1 and checks the fp32 first layer
+    folded = ex.first_layers_folded
     collect = [dict() for _ in range(x.shape[0])]
-    want = np.stack([oext.vgg_pyramid(x[f], params, pad_top=pad_top, collect=collect[f],
-                                      conv_dtype='bf16') for f in range(x.shape[0])])
+    want = np.stack([oext.vgg_pyramid(x[f], params, pad_top=pad_top, collect=collect[f], conv_dtype='bf16',
+                                      first_layer='split' if folded else 'fp32') for f in range(x.shape[0])])
     for name in synth.PYRAMID_LAYERS[:-1]:
         w = np.stack([c[name] for c in collect])
+        if folded and name == 'conv1_1':
+            with pytest.raises(ValueError, match='folded'):
+                ex.activation(name)
+            continue
         got = ex.activation(name)
         assert np.array_equal(got, tfops.round_bf16(got)), name   # stored maps ARE bf16
         _bars(got, w, name)
@@ -49,6 +57,8 @@ def _run(cls, x, params, pad_top):
     rel = np.abs(feat - f32).max() / (np.abs(f32).max() + 1e-12)
     assert rel <= 3e-2, 'bf16 vs fp32 feature maps: %g' % rel
     ex.close()
+    import os
+    assert folded == all(os.environ.get(k, '1') != '0' for k in ('DODT_CONV_BF16_FIRST2', 'DODT_CONV_BF16_STREAM', 'DODT_CONV_BF16_DMA'))
     return rel
 
 
@@ -71,6 +81,26 @@ def test_bf16_is_opt_in_and_checked():
         BevVggPyr(conv_dtype='fp8')
     ex = BevVggPyr()
     assert ex._bf16 is False
+
+
+def _child(env_extra, deselect):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-q',
+                        '-x', '-k', deselect], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_two_launch_first_layers_match_the_same_bars():
+    """By default conv1_1 is computed inside conv1_2's launch (hi + lo bf16 MFMAs on the raw input, conv1_1's map kept
+    in LDS).  DODT_CONV_BF16_FIRST2=0 runs the two layers as two launches (conv1_1 on the fp32 MFMA, its bf16 map stored):
+    every layer, conv1_1 included, against the same bars; DODT_CONV_BF16_STREAM=0 on top puts conv1_2 and pyramid_fusion1
+    back on the chunk-ring kernel."""
+    _child({'DODT_CONV_BF16_FIRST2': '0'}, 'all_layers')
+    _child({'DODT_CONV_BF16_FIRST2': '0', 'DODT_CONV_BF16_STREAM': '0'}, 'all_layers')
 
 
 def test_template_bf16_kernel_matches_the_same_bars():
