@@ -33,7 +33,7 @@ std::vector<KernelVariant> bf16_variants() {
         InstBf16Dma<2, 1, 2>::variant(),      // round 4: 8 x 32 px x 32 channels, three workgroups per CU
         // round 4: producer wave + weights in registers, for the level-1 layers (32 output channels, 2 / 4 chunks)
         InstBf16Stream<2, 2, 8>::variant(),
-        InstBf16Stream<2, 4, 7>::variant(),
+        InstBf16Stream<2, 4, 6>::variant(),
         // round 4: conv1_1 folded into conv1_2 (never picked by shape: dodt_extractor_forward launches it in conv1_2's place)
         InstBf16First2<6, 4>::variant(),
         InstBf16First2<4, 6>::variant(),

@@ -339,7 +339,7 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
 struct StreamTile { int frame, ty0, tx0; };
 template <int MODE, int MT>
 __device__ __forceinline__ void stream_epilogue(const ConvArgs& a, const float* s_par, f32x16 (&acc)[MT], const StreamTile cur,
-                                                int wave, int li, int lh, bool stamp, int* stamps) {
+                                                int wave, int li, int lh, bool stamp, int* stamps, float* s_tile = nullptr) {
     const float floor_v = a.relu ? 0.0f : -3.0e38f;
     {
         f32x4 sc[4], sh[4];
@@ -371,7 +371,25 @@ __device__ __forceinline__ void stream_epilogue(const ConvArgs& a, const float* 
         const bool ok = y < a.H && x < a.W && y >= a.out_y0 && !(a.debug & 1);      // (tools/: 1 = no stores)
         const size_t px = (size_t)(y - a.out_y0) * a.W + x;
         if (MODE == 2) {
-            if (ok) {
+            if (s_tile && a.out_ld == 32 && a.out_coff == 0) {
+                // whole 128-byte pixels per store: the tile goes through the wave's own LDS scratch (32 pixels x 36 dwords)
+                // and comes back with eight lanes per pixel, so that a store instruction writes 1 KB of consecutive bytes
+                // (the accumulator layout gives a lane 16 bytes of every 128: 64 sixteen-byte pieces per instruction --
+                // pyramid_fusion1 spent a third of its time on them)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(s_tile + li * 36 + group_channel<true>(g, lh)) =
+                        f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                const int lane = lh * 32 + li, sub = lane & 7;
+                const bool row_ok = y < a.H && y >= a.out_y0 && !(a.debug & 1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int pp = 8 * m + (lane >> 3);                  // pixel of the tile row
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + pp * 36 + 4 * sub);
+                    if (row_ok && cur.tx0 + pp < a.W)
+                        *reinterpret_cast<f32x4*>(out + ((size_t)(y - a.out_y0) * a.W + cur.tx0 + pp) * 32 + 4 * sub) = v;
+                }
+            } else if (ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<f32x4*>(out + px * a.out_ld + a.out_coff + group_channel<true>(g, lh)) =
@@ -450,7 +468,9 @@ struct Bf16StreamCfg {
     static constexpr int kWFloats = 9 * 2 * BN * 4;                 // a chunk's weights in global memory: [tap][h][n][16 B]
     static constexpr int WR = NCH <= 3 ? NCH : 3;                   // chunks whose weights stay in registers (36 each); the others' in LDS
     static constexpr int kWLdsFloats = (NCH - WR) * kWFloats;
-    static constexpr int kLdsBytes = S * kPatchFloats * 4 + 64 + 384 + kWLdsFloats * 4;     // images | item ring | scale, shift, bottleneck weights | weights
+    static constexpr int kTileFloats = 32 * 36;                     // a wave's scratch for the NHWC stores (stream_epilogue)
+    static constexpr int kLdsBytes = S * kPatchFloats * 4 + 64 + 384 + kWLdsFloats * 4 +
+                                     (NCH == 4 ? 3 * kTileFloats * 4 : 0);   // images | item ring | scale, shift, bottleneck weights | weights | scratch
     static constexpr int kAhead = (NCH - 1 + S) / NCH + 3;          // D: the prologue publishes ring entries 0 .. D - 2, item n >= 1 entry n + D - 2
     static_assert((S - 2) * kCopies <= 63, "vmcnt is six bits");
     static_assert(MT % 2 == 0, "the fused pool pairs the rows of a wave");
@@ -670,7 +690,8 @@ conv3x3_bf16_stream_kernel(const ConvArgs a) {
         const StreamTile cur_t{cur.frame, cur.ty0, cur.tx0};
         if (a.pool_out) stream_epilogue<1, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
         else if (!a.out_nhwc) stream_epilogue<0, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
-        else stream_epilogue<2, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
+        else stream_epilogue<2, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps,
+                                    NCH == 4 ? s_w + Cfg::kWLdsFloats + wave * Cfg::kTileFloats : nullptr);
         if (stamp) { stamps[4] = (int)__builtin_amdgcn_s_memtime(); stamps[5] = stamps[4]; }
     }
 }
