@@ -162,9 +162,11 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         // the small maps: slower, the per-item cost grows faster than the balance improves)
         // the level-1 layers (32 output channels, 2 / 4 chunks): the streaming kernel (DODT_CONV_BF16_STREAM=0: not)
         static const bool stream = !(getenv("DODT_CONV_BF16_STREAM") && atoi(getenv("DODT_CONV_BF16_STREAM")) == 0);
+        // (DODT_CONV_BF16_STREAM_LDS=<KB>: the deepest ring within that much LDS per workgroup; the table lists them deepest first)
+        static const int stream_lds = getenv("DODT_CONV_BF16_STREAM_LDS") ? atoi(getenv("DODT_CONV_BF16_STREAM_LDS")) * 1024 : 1 << 30;
         if (stream && Cout == 32)
             for (size_t i = 0; i < vs.size(); ++i)
-                if (vs[i].stream_nch > 0 && vs[i].stream_nch * 16 == Cin) return (int)i;
+                if (vs[i].stream_nch > 0 && vs[i].stream_nch * 16 == Cin && vs[i].lds_bytes <= stream_lds) return (int)i;
         long best_n = 0;
         static const long per_cu = getenv("DODT_CONV_BF16_ITEMS_PER_CU") ? atol(getenv("DODT_CONV_BF16_ITEMS_PER_CU")) : 4;
         // 8-row tiles (three workgroups per CU) only where the 16-row tiles give fewer than 1.6 items per CU -- the
@@ -814,8 +816,9 @@ int dodt_extractor_create(dodt_ctx* ctx, int kind, int in_h, int in_w, int in_c,
         if (first2 && bf16 && ex->parts == 1 && vs[c12.variant].stream_nch == 2 && c12.tail.n_items == 0 &&
             c11.Cout == 32 && c11.src_coff == 0 && ex->buf[X0].C == c11.Cin && (W * c11.Cin * 4) % 16 == 0 &&
             variant_can_pool(vs[c12.variant]))
-            for (size_t i = 0; i < vs.size(); ++i)
-                if (vs[i].first2 == c11.Cin && vs[i].TH == vs[c12.variant].TH && vs[i].TW == vs[c12.variant].TW)
+            for (size_t i = 0; i < vs.size() && ex->first2_variant < 0; ++i)
+                if (vs[i].first2 == c11.Cin && vs[i].TH == vs[c12.variant].TH && vs[i].TW == vs[c12.variant].TW &&
+                    vs[i].lds_bytes <= (getenv("DODT_CONV_BF16_STREAM_LDS") ? atoi(getenv("DODT_CONV_BF16_STREAM_LDS")) * 1024 : 1 << 30))
                     ex->first2_variant = (int)i;
     }
     if (getenv("DODT_DEBUG_PLAN")) {

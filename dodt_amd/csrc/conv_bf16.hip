@@ -34,9 +34,17 @@ std::vector<KernelVariant> bf16_variants() {
         // round 4: producer wave + weights in registers, for the level-1 layers (32 output channels, 2 / 4 chunks)
         InstBf16Stream<2, 2, 8>::variant(),
         InstBf16Stream<2, 4, 6>::variant(),
+        // (shallower rings, less LDS: DODT_CONV_BF16_STREAM_LDS=<KB> picks the deepest ring that fits -- tools/)
+        InstBf16Stream<2, 2, 5>::variant(),
+        InstBf16Stream<2, 2, 3>::variant(),
+        InstBf16Stream<2, 4, 4>::variant(),
+        InstBf16Stream<2, 4, 3>::variant(),
         // round 4: conv1_1 folded into conv1_2 (never picked by shape: dodt_extractor_forward launches it in conv1_2's place)
         InstBf16First2<6, 4>::variant(),
         InstBf16First2<4, 6>::variant(),
+        InstBf16First2<6, 3>::variant(),
+        InstBf16First2<4, 4>::variant(),
+        InstBf16First2<4, 3>::variant(),
         // round 3: the LDS-DMA staged transposed conv on v_mfma_f32_16x16x16_bf16 (deconv_kernel.h)
         InstDeconvDma<2, true>::variant(),
         InstDeconvDma<1, true>::variant(),

@@ -32,6 +32,123 @@
 
 namespace dodt {
 
+// Epilogue of the kernels of this file for one item: batch-norm + ReLU, stores, fused 2x2 pool / 1x1 bottleneck -- what
+// store_tile / pool_tile of conv_kernels.h do for the other kernels, with the per-channel parameters (s_par: scale[32],
+// shift[32], bottleneck weights[32]) read from LDS in one batch (an item is 1-2 us here: eight dependent parameter loads per
+// tile were twice the MFMAs' time) and the pool's horizontal neighbour taken by DPP.
+// MODE 0: CB16 bf16 map, 1: the same + its 2x2 max pool, 2: NHWC fp32 (+ bottleneck).  Returns nothing; `mid` (optional
+// diagnostic) receives s_memtime between the stores and the pool.
+struct StreamTile { int frame, ty0, tx0; };
+// p_scale / p_shift / p_bw: the channel tile's batch-norm scale, shift and bottleneck weights (LDS or global memory: read in
+// one batch either way); c0: the tile's first channel; acc: tile mt of channel tile NTI is acc[mt * NT + NTI].
+template <int MODE, int MT, int NT = 1, int NTI = 0>
+__device__ __forceinline__ void stream_epilogue(const ConvArgs& a, const float* p_scale, const float* p_shift, const float* p_bw,
+                                                f32x16 (&acc_all)[MT * NT], const StreamTile cur, int c0, int wave, int li, int lh,
+                                                bool stamp, int* stamps, float* s_tile = nullptr) {
+    auto acc = [&](int mt) -> f32x16& { return acc_all[mt * NT + NTI]; };
+    const float floor_v = a.relu ? 0.0f : -3.0e38f;
+    {
+        f32x4 sc[4], sh[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = group_channel<true>(g, lh);
+            sc[g] = *reinterpret_cast<const f32x4*>(p_scale + c);
+            sh[g] = *reinterpret_cast<const f32x4*>(p_shift + c);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc(mt)[r] = fmaxf(acc(mt)[r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], floor_v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int out_rows = a.H - a.out_y0;
+    const long long plane = (long long)out_rows * a.W * 8;
+    float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
+    const int x = cur.tx0 + li;
+    f32x4 bw[4];      // (read when the scales are dead: the 64-channel instance has 144 registers of weights)
+    if (MODE == 2 && a.bneck_w) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[g] = *reinterpret_cast<const f32x4*>(p_bw + group_channel<true>(g, lh));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int y = cur.ty0 + wave * MT + mt;
+        const bool ok = y < a.H && x < a.W && y >= a.out_y0 && !(a.debug & 1);      // (tools/: 1 = no stores)
+        const size_t px = (size_t)(y - a.out_y0) * a.W + x;
+        if (MODE == 2) {
+            if (s_tile && a.out_ld == 32 && a.out_coff == 0 && c0 == 0) {
+                // whole 128-byte pixels per store: the tile goes through the wave's own LDS scratch (32 pixels x 36 dwords)
+                // and comes back with eight lanes per pixel, so that a store instruction writes 1 KB of consecutive bytes
+                // (the accumulator layout gives a lane 16 bytes of every 128: 64 sixteen-byte pieces per instruction --
+                // pyramid_fusion1 spent a third of its time on them)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(s_tile + li * 36 + group_channel<true>(g, lh)) =
+                        f32x4{acc(mt)[4 * g], acc(mt)[4 * g + 1], acc(mt)[4 * g + 2], acc(mt)[4 * g + 3]};
+                const int lane = lh * 32 + li, sub = lane & 7;
+                const bool row_ok = y < a.H && y >= a.out_y0 && !(a.debug & 1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int pp = 8 * m + (lane >> 3);                  // pixel of the tile row
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + pp * 36 + 4 * sub);
+                    if (row_ok && cur.tx0 + pp < a.W)
+                        *reinterpret_cast<f32x4*>(out + ((size_t)(y - a.out_y0) * a.W + cur.tx0 + pp) * 32 + 4 * sub) = v;
+                }
+            } else if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(out + px * a.out_ld + a.out_coff + c0 + group_channel<true>(g, lh)) =
+                        f32x4{acc(mt)[4 * g], acc(mt)[4 * g + 1], acc(mt)[4 * g + 2], acc(mt)[4 * g + 3]};
+            }
+            if (a.bneck_w) {
+                float dot = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot += acc(mt)[r] * bw[r >> 2][r & 3];
+                dot += __shfl_xor(dot, 32, 64);          // the other 16 channels of this pixel live in lane ^ 32
+                if (ok && lh == 0)
+                    a.bneck_out[(size_t)cur.frame * a.bneck_frame_stride + px] =
+                        fmaxf(dot * a.bneck_scale + a.bneck_shift, 0.0f);
+            }
+        } else if (ok) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)       // groups (2 gp, 2 gp + 1): 8 consecutive channels = one 16-byte store
+                *reinterpret_cast<f32x4*>(out + (size_t)((a.out_coff + c0 + 16 * gp) >> 4) * plane + px * 8 + 4 * lh) =
+                    f32x4{pack_bf16(acc(mt)[8 * gp], acc(mt)[8 * gp + 1]), pack_bf16(acc(mt)[8 * gp + 2], acc(mt)[8 * gp + 3]),
+                          pack_bf16(acc(mt)[8 * gp + 4], acc(mt)[8 * gp + 5]), pack_bf16(acc(mt)[8 * gp + 6], acc(mt)[8 * gp + 7])};
+        }
+    }
+    if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+    if (MODE == 1) {
+        // VALID 2x2 pool of the activated rows (mt, mt + 1): vertical neighbour = the same lane of the next row,
+        // horizontal = lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes at even (y, x) store
+        const int OW = a.W >> 1;
+        const long long pplane = (long long)(a.H >> 1) * OW * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt += 2) {
+            const int y = cur.ty0 + wave * MT + mt;
+            const bool writer = y < a.H && x < a.W && !(y & 1) && !(x & 1) && y + 1 < a.H && x + 1 < a.W && !(a.debug & 1);
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = fmaxf(acc(mt)[r], acc(mt + 1)[r]);
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                    0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
+                m[r] = fmaxf(t, o);
+            }
+            if (writer) {
+                float* base = a.pool_out + (size_t)cur.frame * a.pool_frame_stride +
+                              ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp)
+                    *reinterpret_cast<f32x4*>(base + (size_t)((c0 >> 4) + gp) * pplane) =
+                        f32x4{pack_bf16(m[8 * gp], m[8 * gp + 1]), pack_bf16(m[8 * gp + 2], m[8 * gp + 3]),
+                              pack_bf16(m[8 * gp + 4], m[8 * gp + 5]), pack_bf16(m[8 * gp + 6], m[8 * gp + 7])};
+            }
+        }
+    }
+}
+
 template <int MT, int NT, int S>
 struct Bf16DmaCfg {
     static_assert(S >= 2 && S <= 4, "ring of 2..4 chunk images");
@@ -211,7 +328,9 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         const bool stamp = (a.debug & 32) && blockIdx.x == 1 && tid == 0 && k_stamp < 12;
         int* stamps = a.counter_base + 32 + (k_stamp < 12 ? k_stamp : 0) * 6;
         if (stamp) { stamps[0] = (int)__builtin_amdgcn_s_memtime(); stamps[1] = stamps[0]; stamps[2] = stamps[0]; }
-        if (comp_ch == 0 && tid == 0) s_ctrl[0] = ticket_item(atomicAdd(q_counter, 1));
+        // (the ticket is drawn here and published at the end of the step: the atomic's round trip hides behind the MFMAs)
+        int ticket = 0;
+        if (comp_ch == 0 && tid == 0) ticket = atomicAdd(q_counter, 1);
         const float* sP = smem + PAR * Cfg::kBufFloats + row0;
         const float* sW = smem + PAR * Cfg::kBufFloats + Cfg::kPatchFloats + w_lane;
         f32x4 x[MT + 2], w[2][NT];
@@ -252,6 +371,7 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
+        if (comp_ch == 0 && tid == 0) s_ctrl[0] = ticket_item(ticket);
         __builtin_amdgcn_s_waitcnt(0);        // the copies of chunk k+1 have landed
         if (stamp) stamps[4] = (int)__builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
@@ -273,45 +393,66 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
         // the asm MFMAs are opaque to the hazard recogniser: 16-pass results need 18 wait states
 #pragma unroll
         for (int k = 0; k < MT * NT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
-        // ---- epilogue (as in conv3x3_mfma_kernel): BN + ReLU, stores, fused pool / bottleneck ---
-        const Item cur = decode(k0);
-        float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
-        const int out_rows = a.H - a.out_y0;
-        const long long plane = (long long)out_rows * a.W * 8;
-        const bool pool = a.pool_out != nullptr;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int y = cur.ty0 + wave * MT + mt;
-            const int x = cur.tx0 + li;
-            const bool ok = y < a.H && x < a.W && y >= a.out_y0;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int c0 = cur.ntile * BN + nt * 32;
-                if (pool)
-                    store_tile<true, true, true, false>(a, out, acc[mt * NT + nt], c0, lh,
-                                                        y - a.out_y0, x, a.W, plane, ok, cur.frame);
-                else if (!a.out_nhwc)
-                    store_tile<false, true, true, false>(a, out, acc[mt * NT + nt], c0, lh,
-                                                         y - a.out_y0, x, a.W, plane, ok, cur.frame);
-                else
-                    store_tile<false, true, false>(a, out, acc[mt * NT + nt], c0, lh, y - a.out_y0,
-                                                   x, a.W, plane, ok, cur.frame);
-                // one accumulator tile at a time: they live in AGPRs and pass through VGPRs here
+        if constexpr (NT == 1) {
+            // ---- epilogue: BN + ReLU, stores, fused pool / bottleneck (stream_epilogue above: a channel tile's parameters in one
+            // batch of loads -- store_tile's two loads and a wait per group of four channels, sixteen times per item, were a
+            // third of a mid layer's item time)
+            const Item cur = decode(k0);
+            const StreamTile cur_t{cur.frame, cur.ty0, cur.tx0};
+            const bool pool = a.pool_out != nullptr;
+            auto channel_tile = [&](auto nt_c) {
+                constexpr int NTI = decltype(nt_c)::value;
+                const int c0 = cur.ntile * BN + NTI * 32;
+                const float* bw = a.bneck_w ? a.bneck_w + c0 : a.scale + c0;      // (read only with a bottleneck)
+                if (pool) stream_epilogue<1, MT, NT, NTI>(a, a.scale + c0, a.shift + c0, bw, acc, cur_t, c0, wave, li, lh, false, nullptr);
+                else if (!a.out_nhwc) stream_epilogue<0, MT, NT, NTI>(a, a.scale + c0, a.shift + c0, bw, acc, cur_t, c0, wave, li, lh, false, nullptr);
+                else stream_epilogue<2, MT, NT, NTI>(a, a.scale + c0, a.shift + c0, bw, acc, cur_t, c0, wave, li, lh, false, nullptr);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (pool) {
+            };
+            channel_tile(std::integral_constant<int, 0>{});
+            if constexpr (NT == 2) channel_tile(std::integral_constant<int, 1>{});
+        } else {
+            // (two channel tiles per wave: 128 accumulators leave no room for a batch of parameters -- store_tile's form)
+            // ---- epilogue (as in conv3x3_mfma_kernel): BN + ReLU, stores, fused pool / bottleneck ---
+            const Item cur = decode(k0);
+            float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
+            const int out_rows = a.H - a.out_y0;
+            const long long plane = (long long)out_rows * a.W * 8;
+            const bool pool = a.pool_out != nullptr;
 #pragma unroll
-            for (int mt = 0; mt < MT; mt += 2) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const int y = cur.ty0 + wave * MT + mt;
                 const int x = cur.tx0 + li;
-                const bool ok = y < a.H && x < a.W;
+                const bool ok = y < a.H && x < a.W && y >= a.out_y0;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                {
-                    pool_tile<32, true, true, false>(a, acc[mt * NT + nt], acc[(mt + 1) * NT + nt],
-                                                     cur.ntile * BN + nt * 32, lh, y, x, cur.frame, ok);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c0 = cur.ntile * BN + nt * 32;
+                    if (pool)
+                        store_tile<true, true, true, false>(a, out, acc[mt * NT + nt], c0, lh,
+                                                            y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                    else if (!a.out_nhwc)
+                        store_tile<false, true, true, false>(a, out, acc[mt * NT + nt], c0, lh,
+                                                             y - a.out_y0, x, a.W, plane, ok, cur.frame);
+                    else
+                        store_tile<false, true, false>(a, out, acc[mt * NT + nt], c0, lh, y - a.out_y0,
+                                                       x, a.W, plane, ok, cur.frame);
+                    // one accumulator tile at a time: they live in AGPRs and pass through VGPRs here
                     __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (pool) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt += 2) {
+                    const int y = cur.ty0 + wave * MT + mt;
+                    const int x = cur.tx0 + li;
+                    const bool ok = y < a.H && x < a.W;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                    {
+                        pool_tile<32, true, true, false>(a, acc[mt * NT + nt], acc[(mt + 1) * NT + nt],
+                                                         cur.ntile * BN + nt * 32, lh, y, x, cur.frame, ok);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
@@ -329,119 +470,6 @@ conv3x3_bf16_dma_kernel(const ConvArgs a) {
     }
 }
 
-
-// Epilogue of the streaming kernels for one item: batch-norm + ReLU, stores, fused 2x2 pool / 1x1 bottleneck -- what
-// store_tile / pool_tile of conv_kernels.h do for the other kernels, with the per-channel parameters (s_par: scale[32],
-// shift[32], bottleneck weights[32]) read from LDS in one batch (an item is 1-2 us here: eight dependent parameter loads per
-// tile were twice the MFMAs' time) and the pool's horizontal neighbour taken by DPP.
-// MODE 0: CB16 bf16 map, 1: the same + its 2x2 max pool, 2: NHWC fp32 (+ bottleneck).  Returns nothing; `mid` (optional
-// diagnostic) receives s_memtime between the stores and the pool.
-struct StreamTile { int frame, ty0, tx0; };
-template <int MODE, int MT>
-__device__ __forceinline__ void stream_epilogue(const ConvArgs& a, const float* s_par, f32x16 (&acc)[MT], const StreamTile cur,
-                                                int wave, int li, int lh, bool stamp, int* stamps, float* s_tile = nullptr) {
-    const float floor_v = a.relu ? 0.0f : -3.0e38f;
-    {
-        f32x4 sc[4], sh[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = group_channel<true>(g, lh);
-            sc[g] = *reinterpret_cast<const f32x4*>(s_par + c);
-            sh[g] = *reinterpret_cast<const f32x4*>(s_par + 32 + c);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[mt][r] = fmaxf(acc[mt][r] * sc[r >> 2][r & 3] + sh[r >> 2][r & 3], floor_v);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int out_rows = a.H - a.out_y0;
-    const long long plane = (long long)out_rows * a.W * 8;
-    float* out = a.out + (size_t)cur.frame * a.out_frame_stride;
-    const int x = cur.tx0 + li;
-    f32x4 bw[4];      // (read when the scales are dead: the 64-channel instance has 144 registers of weights)
-    if (MODE == 2 && a.bneck_w) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bw[g] = *reinterpret_cast<const f32x4*>(s_par + 64 + group_channel<true>(g, lh));
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int y = cur.ty0 + wave * MT + mt;
-        const bool ok = y < a.H && x < a.W && y >= a.out_y0 && !(a.debug & 1);      // (tools/: 1 = no stores)
-        const size_t px = (size_t)(y - a.out_y0) * a.W + x;
-        if (MODE == 2) {
-            if (s_tile && a.out_ld == 32 && a.out_coff == 0) {
-                // whole 128-byte pixels per store: the tile goes through the wave's own LDS scratch (32 pixels x 36 dwords)
-                // and comes back with eight lanes per pixel, so that a store instruction writes 1 KB of consecutive bytes
-                // (the accumulator layout gives a lane 16 bytes of every 128: 64 sixteen-byte pieces per instruction --
-                // pyramid_fusion1 spent a third of its time on them)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(s_tile + li * 36 + group_channel<true>(g, lh)) =
-                        f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                const int lane = lh * 32 + li, sub = lane & 7;
-                const bool row_ok = y < a.H && y >= a.out_y0 && !(a.debug & 1);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int pp = 8 * m + (lane >> 3);                  // pixel of the tile row
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(s_tile + pp * 36 + 4 * sub);
-                    if (row_ok && cur.tx0 + pp < a.W)
-                        *reinterpret_cast<f32x4*>(out + ((size_t)(y - a.out_y0) * a.W + cur.tx0 + pp) * 32 + 4 * sub) = v;
-                }
-            } else if (ok) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(out + px * a.out_ld + a.out_coff + group_channel<true>(g, lh)) =
-                        f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-            }
-            if (a.bneck_w) {
-                float dot = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dot += acc[mt][r] * bw[r >> 2][r & 3];
-                dot += __shfl_xor(dot, 32, 64);          // the other 16 channels of this pixel live in lane ^ 32
-                if (ok && lh == 0)
-                    a.bneck_out[(size_t)cur.frame * a.bneck_frame_stride + px] =
-                        fmaxf(dot * a.bneck_scale + a.bneck_shift, 0.0f);
-            }
-        } else if (ok) {
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp)       // groups (2 gp, 2 gp + 1): 8 consecutive channels = one 16-byte store
-                *reinterpret_cast<f32x4*>(out + (size_t)((a.out_coff + 16 * gp) >> 4) * plane + px * 8 + 4 * lh) =
-                    f32x4{pack_bf16(acc[mt][8 * gp], acc[mt][8 * gp + 1]), pack_bf16(acc[mt][8 * gp + 2], acc[mt][8 * gp + 3]),
-                          pack_bf16(acc[mt][8 * gp + 4], acc[mt][8 * gp + 5]), pack_bf16(acc[mt][8 * gp + 6], acc[mt][8 * gp + 7])};
-        }
-    }
-    if (stamp) stamps[3] = (int)__builtin_amdgcn_s_memtime();
-    if (MODE == 1) {
-        // VALID 2x2 pool of the activated rows (mt, mt + 1): vertical neighbour = the same lane of the next row,
-        // horizontal = lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes at even (y, x) store
-        const int OW = a.W >> 1;
-        const long long pplane = (long long)(a.H >> 1) * OW * 8;
-#pragma unroll
-        for (int mt = 0; mt < MT; mt += 2) {
-            const int y = cur.ty0 + wave * MT + mt;
-            const bool writer = y < a.H && x < a.W && !(y & 1) && !(x & 1) && y + 1 < a.H && x + 1 < a.W && !(a.debug & 1);
-            float m[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float t = fmaxf(acc[mt][r], acc[mt + 1][r]);
-                const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                    0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
-                m[r] = fmaxf(t, o);
-            }
-            if (writer) {
-                float* base = a.pool_out + (size_t)cur.frame * a.pool_frame_stride +
-                              ((size_t)(y >> 1) * OW + (x >> 1)) * 8 + 4 * lh;
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp)
-                    *reinterpret_cast<f32x4*>(base + (size_t)gp * pplane) =
-                        f32x4{pack_bf16(m[8 * gp], m[8 * gp + 1]), pack_bf16(m[8 * gp + 2], m[8 * gp + 3]),
-                              pack_bf16(m[8 * gp + 4], m[8 * gp + 5]), pack_bf16(m[8 * gp + 6], m[8 * gp + 7])};
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Round 4, late: the level-1 layers (32 output channels, 32 or 64 input channels: conv1_2, pyramid_fusion1 -- 0.25 of
@@ -688,9 +716,9 @@ conv3x3_bf16_stream_kernel(const ConvArgs a) {
         for (int k = 0; k < MT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
         const Item cur = decode(item);
         const StreamTile cur_t{cur.frame, cur.ty0, cur.tx0};
-        if (a.pool_out) stream_epilogue<1, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
-        else if (!a.out_nhwc) stream_epilogue<0, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps);
-        else stream_epilogue<2, MT>(a, s_par, acc, cur_t, wave, li, lh, stamp, stamps,
+        if (a.pool_out) stream_epilogue<1, MT>(a, s_par, s_par + 32, s_par + 64, acc, cur_t, 0, wave, li, lh, stamp, stamps);
+        else if (!a.out_nhwc) stream_epilogue<0, MT>(a, s_par, s_par + 32, s_par + 64, acc, cur_t, 0, wave, li, lh, stamp, stamps);
+        else stream_epilogue<2, MT>(a, s_par, s_par + 32, s_par + 64, acc, cur_t, 0, wave, li, lh, stamp, stamps,
                                     NCH == 4 ? s_w + Cfg::kWLdsFloats + wave * Cfg::kTileFloats : nullptr);
         if (stamp) { stamps[4] = (int)__builtin_amdgcn_s_memtime(); stamps[5] = stamps[4]; }
     }
@@ -1038,8 +1066,8 @@ conv3x3_bf16_first2_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < MT; ++k) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[k]));
         if (stamp) stamps[2] = (int)__builtin_amdgcn_s_memtime();
-        if (a.pool_out) stream_epilogue<1, MT>(a, s_par, acc, cur, cw, li, lh, stamp, stamps);
-        else stream_epilogue<0, MT>(a, s_par, acc, cur, cw, li, lh, stamp, stamps);
+        if (a.pool_out) stream_epilogue<1, MT>(a, s_par, s_par + 32, s_par + 64, acc, cur, 0, cw, li, lh, stamp, stamps);
+        else stream_epilogue<0, MT>(a, s_par, s_par + 32, s_par + 64, acc, cur, 0, cw, li, lh, stamp, stamps);
         if (stamp) { stamps[4] = (int)__builtin_amdgcn_s_memtime(); stamps[5] = stamps[4]; }
         slot = slot + 1 == S ? 0 : slot + 1;
         asm volatile("s_barrier" ::: "memory");   // X_{n+1}

@@ -159,6 +159,9 @@ class FramePairPipeline(object):
                                             if self.fps == 2 else None)
                                        for _ in sides] for sides, _ in self.stream_sets]
             self.head_scratch = self.head_scratch_sets[0]
+            # the pairs' correlation maps, by step parity (written behind the image stack on its stream, see run())
+            self.corr_maps = [[ctx.empty((self.bev_fh, self.bev_fw, CORR_CH), f32) for _ in range(self.pairs)]
+                              for _ in range(2)] if self.fps == 2 else None
 
         # ---- work buffers ----------------------------------------------------------------
         FC = self.feat_c
@@ -399,6 +402,25 @@ class FramePairPipeline(object):
         self.img_net.forward_device_padded(self.in_img[cur], feat['img_feat'], feat['img_bneck'])
         self._mark(main, k, 'bev_end')
         self._mark(self.img_ctx, k, 'img_end')
+        # The tail of THIS step (next call) starts when these convs are done.  The point is marked now and waited
+        # for when the tail is enqueued -- behind the NEXT step's prep on the same side stream, which therefore
+        # runs under these convs instead of behind them (DODT_PIPE_EARLY_PREP=0: the wait goes in at the end of this
+        # call, in front of that prep, as before round 3)
+        main.mark(self.CONV_DONE_MARK + cur)
+        self.img_ctx.mark(self.CONV_DONE_MARK + cur)
+        # The T branch's correlation map needs the two frames' BEV maps and nothing else: it runs HERE, behind the image
+        # stack on its stream (the shorter of the two stacks), not inside a frame's tail, whose dependent launch chain
+        # -- with its prep what bounds the bf16 step -- it made 50 us longer (DODT_PIPE_CORR_MAP=f1: round 4's first form,
+        # map and crops on frame 1's stream between its crops and its head, the correlation head on frame 0's)
+        if self._corr_on_img():
+            self.img_ctx.wait_mark(main, self.CONV_DONE_MARK + cur)
+            bev_hw, px = (self.bev_fh, self.bev_fw), self.bev_fh * self.bev_fw
+            for pair in range(self.pairs):
+                fb0 = feat['bev_feat'].offset(4 * px * self.feat_c * (2 * pair), bev_hw + (self.feat_c,))
+                fb1 = feat['bev_feat'].offset(4 * px * self.feat_c * (2 * pair + 1), bev_hw + (self.feat_c,))
+                ops.correlation(self.img_ctx, fb0, fb1, bev_hw + (self.feat_c,), CORR_MAX_DISP, CORR_STRIDE2, CORR_PAD,
+                                self.corr_maps[cur][pair])
+            self.img_ctx.mark(self.CORR_MAP_MARK + cur)
         # -- the next step's prep, when the caller has given its inputs: in front of the previous step's tail ----
         if lookahead is not None:
             la = tuple(lookahead) + (None,) * (4 - len(lookahead))
@@ -424,12 +446,6 @@ class FramePairPipeline(object):
                 if p_preps[i] is not s:
                     p_preps[i].wait_mark(s, self.TAIL_DONE_MARK)
         self.pending = dict(cur=cur, heads=heads, step=k, rslot=k % len(self.rec2))
-        # The tail of THIS step (next call) starts when these convs are done.  The point is marked now and waited
-        # for when the tail is enqueued -- behind the NEXT step's prep on the same side stream, which therefore
-        # runs under these convs instead of behind them (DODT_PIPE_EARLY_PREP=0: the wait goes in here, in front
-        # of that prep, as before round 3)
-        main.mark(self.CONV_DONE_MARK + cur)
-        self.img_ctx.mark(self.CONV_DONE_MARK + cur)
         if not self.early_prep:
             for s in sides:
                 s.wait_for(main)
@@ -449,6 +465,13 @@ class FramePairPipeline(object):
         self.ctx.wait_for(self.img_ctx)
 
     CONV_DONE_MARK = 250        # mark slots 250, 251 of the conv contexts: end of a step's stacks, by parity
+    CORR_MAP_MARK = 248         # ... 248, 249 of the image context: the step's correlation maps stand, by parity
+
+    def _corr_on_img(self):
+        """The T branch's correlation runs behind the image stack (run()) instead of inside a frame's tail."""
+        return (self.rpn_head is not None and self.fps == 2 and len(self.sides) >= 2
+                and not os.environ.get('DODT_PIPE_NO_CORR') and os.environ.get('DODT_PIPE_CORR_ON_F1', '1') != '0'
+                and os.environ.get('DODT_PIPE_CORR_MAP', 'img') == 'img')
 
     def _wait_convs(self, st):
         """The side streams wait for the conv stacks of step `st` (marked at the end of its run())."""
@@ -493,6 +516,7 @@ class FramePairPipeline(object):
         # 0's rest (DODT_PIPE_CORR_ON_F1=0: all of the branch on frame 0's stream).
         split_t = computed and self.fps == 2 and ns >= 2 and not os.environ.get('DODT_PIPE_NO_CORR') \
             and os.environ.get('DODT_PIPE_CORR_ON_F1', '1') != '0'
+        corr_img = split_t and self._corr_on_img()
 
         def t_branch_crops(cc, f0, scratch):
             """Correlation map of pair (f0, f0 + 1) and its 7x7 crops at frame f0's proposals, on context cc."""
@@ -555,13 +579,16 @@ class FramePairPipeline(object):
                 if pair and f % 2 == 0 and not os.environ.get('DODT_PIPE_NO_CORR'):
                     # T branch: correlate the pair's BEV features, crop with frame 0's
                     # proposals (dt_rpn_model.py:324-331, dt_avod_model.py:267-273,300-304)
-                    if split_t:
-                        c.wait_mark(sides[(f + 1) % ns], self.CORR_ROIS_MARK)
+                    if corr_img:
+                        pass        # (crops and head on frame 1's stream, below; the records wait for them)
                     else:
-                        t_branch_crops(c, f, scratch)
-                    self._mark(c, st['step'], 'tail%d_corrmap' % f)
-                    self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
-                                           [b['corr_offsets']], scratch['fc'])
+                        if split_t:
+                            c.wait_mark(sides[(f + 1) % ns], self.CORR_ROIS_MARK)
+                        else:
+                            t_branch_crops(c, f, scratch)
+                        self._mark(c, st['step'], 'tail%d_corrmap' % f)
+                        self.corr_head.forward(c, b['corr_rois'], None, self.P, b['top_count'],
+                                               [b['corr_offsets']], scratch['fc'])
             self._mark(c, st['step'], 'tail%d_heads' % f)
             # -- a14, a13: box_4c decode, NMS #2 ---------------------------------------------
             ops.box_4c_decode(c, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
@@ -578,6 +605,7 @@ class FramePairPipeline(object):
             if self.box_4ca:
                 ops.angle_vector_to_orientation(c, h['angle_vectors'], self.P, b['top_count'],
                                                 b['orientations'])
+            yield 'pack'
             ops.pack_detections(
                 c, b['boxes_3d'], b['det_scores'], b['det_idx'], b['det_count'], MAX_DET,
                 float(f % self.fps),
@@ -600,6 +628,26 @@ class FramePairPipeline(object):
             while next(g0) != 'crops':          # frame 0 up to its 7x7 crops: its proposals stand
                 pass
             c0.mark(self.PROPOSALS_MARK)
+            if corr_img:
+                # The map stands since the convs ended (run()).  Its crops at frame 0's proposals and the correlation head
+                # go onto frame 1's stream, in front of that frame's own head -- frame 0's stream, which carried them,
+                # was the longer chain by their 0.1 ms -- and frame 0's records wait for the offsets.
+                while next(g0) != 'pack':
+                    pass
+                while next(g1) != 'crops':
+                    pass
+                c1.wait_mark(c0, self.PROPOSALS_MARK)
+                c1.wait_mark(self.img_ctx, self.CORR_MAP_MARK + cur)
+                ops.crop_and_resize(c1, self.corr_maps[cur][f0 // 2], bev_hw + (CORR_CH,), fr[f0]['top_bev'], self.P,
+                                    fr[f0]['top_count'], (ROI, ROI), fr[f0]['corr_rois'],
+                                    out_box_stride=self.corr_head.in_ld)
+                self.corr_head.forward(c1, fr[f0]['corr_rois'], None, self.P, fr[f0]['top_count'],
+                                       [fr[f0]['corr_offsets']], head_scratch[(f0 + 1) % ns]['fc'])
+                c1.mark(self.CORR_ROIS_MARK)
+                c0.wait_mark(c1, self.CORR_ROIS_MARK)
+                drain(g0)
+                drain(g1)
+                continue
             while next(g0) != 'head':           # ... and its stage-2 head
                 pass
             while next(g1) != 'crops':          # frame 1 up to its crops, then the T branch's map and crops
