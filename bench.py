@@ -280,7 +280,7 @@ def _group_by_kernel(layers):
         k = out.setdefault(l['kernel'], dict(kernel=l['kernel'], launches=0, ms=0.0, flops_executed=0.0,
                                              flops_direct=0.0, bytes=0.0, layers=[]))
         k['launches'] += l['launches']
-        k['ms'] += l['ms']
+        k['ms'] += l['ms'] if l['launches'] else 0.0      # (a folded layer's event pair brackets nothing)
         k['flops_executed'] += l['flops_executed']
         k['flops_direct'] += l['flops_direct']
         k['bytes'] += l['bytes']
@@ -811,9 +811,12 @@ def main():
                          side_by_side_ms=round(m['both_ms'], 4),
                          side_by_side_direct_equivalent_tflops=round(m['flops'] / (m['both_ms'] * 1e-3) / 1e12, 2)),
         kernels=kernels,
+        # (a layer with no launch of its own -- conv1_1 folded into conv1_2's launch on the bf16 conv path -- lists its
+        #  FLOPs with `us` null: its time is inside the next row's)
         layers=[dict(net='bev' if i < len(m['layers']) // 2 else 'img', name=l['name'], kernel=l['kernel'],
-                     items=l['items'], us=round(l['ms'] * 1e3, 1),
-                     executed_tflops=round(l['flops_executed'] / (l['ms'] * 1e-3) / 1e12, 1))
+                     items=l['items'], us=round(l['ms'] * 1e3, 1) if l['launches'] else None,
+                     executed_tflops=round(l['flops_executed'] / (l['ms'] * 1e-3) / 1e12, 1) if l['launches'] else None,
+                     **({} if l['launches'] else {'folded_into_next': True}))
                 for i, l in enumerate(m['layers'])])
     hbm = m.get('hbm')
     if hbm:

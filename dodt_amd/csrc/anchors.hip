@@ -16,51 +16,40 @@ namespace {
 // at most ~43 x 43 cells, so the same count comes from popcounts over the
 // voxeliser's bit grid (70 KB, L2 resident) with no table to build.
 // ---------------------------------------------------------------------------
-// Eight lanes per anchor (round 4: one lane per anchor walked up to 43 rows x 3 words of L2-resident bits one after the
-// other -- 48 us on a frame's prep chain, whose length bounds the bf16 step): lane `sub` counts rows z1 + sub, z1 + sub + 8,
-// ...; a block still covers anchors 256 b .. 256 b + 255 (block_counts feeds anchor_compact_kernel), in eight rounds of 32.
+__device__ __forceinline__ int box_count(const uint32_t* __restrict__ occ, int wpr, int x1,
+                                         int z1, int x2, int z2, int thr) {
+    int cnt = 0;
+    if (x2 <= x1) return 0;
+    const int w0 = x1 >> 5, w1 = (x2 - 1) >> 5;
+    for (int z = z1; z < z2; ++z) {
+        for (int w = w0; w <= w1; ++w) {
+            uint32_t word = occ[z * wpr + w];
+            const int lo = (w == w0) ? (x1 & 31) : 0;
+            const int hi = (w == w1) ? ((x2 - 1) & 31) : 31;
+            uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            cnt += __popc(word & m);
+        }
+        if (cnt >= thr) return cnt;
+    }
+    return cnt;
+}
+
 __global__ void __launch_bounds__(256)
 anchor_mask_kernel(const uint32_t* __restrict__ occ, int wpr, int nx, int nz,
                    const int4* __restrict__ cells, int n, int thr,
                    uint8_t* __restrict__ mask, int* __restrict__ block_counts) {
-    __shared__ int s_total;
-    if (threadIdx.x == 0) s_total = 0;
-    __syncthreads();
-    const int sub = threadIdx.x & 7;
-    int kept = 0;
-#pragma unroll 2
-    for (int r = 0; r < 8; ++r) {
-        const int i = blockIdx.x * 256 + r * 32 + (threadIdx.x >> 3);
-        int cnt = 0;
-        if (i < n) {
-            const int4 b = cells[i];
-            // IntegralImage2D.query clamps to the table size again (:71-76)
-            const int x1 = min(max(b.x, 0), nx), z1 = min(max(b.y, 0), nz);
-            const int x2 = min(max(b.z, 0), nx), z2 = min(max(b.w, 0), nz);
-            if (x2 > x1) {
-                const int w0 = x1 >> 5, w1 = (x2 - 1) >> 5;
-                for (int z = z1 + sub; z < z2; z += 8)
-                    for (int w = w0; w <= w1; ++w) {
-                        const uint32_t word = occ[z * wpr + w];
-                        const int lo = (w == w0) ? (x1 & 31) : 0;
-                        const int hi = (w == w1) ? ((x2 - 1) & 31) : 31;
-                        const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                        cnt += __popc(word & m);
-                    }
-            }
-        }
-        cnt += __shfl_xor(cnt, 1, 64);
-        cnt += __shfl_xor(cnt, 2, 64);
-        cnt += __shfl_xor(cnt, 4, 64);
-        if (sub == 0 && i < n) {
-            const int keep = cnt >= thr;
-            mask[i] = (uint8_t)keep;
-            kept += keep;
-        }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int keep = 0;
+    if (i < n) {
+        int4 b = cells[i];
+        // IntegralImage2D.query clamps to the table size again (:71-76)
+        const int x1 = min(max(b.x, 0), nx), z1 = min(max(b.y, 0), nz);
+        const int x2 = min(max(b.z, 0), nx), z2 = min(max(b.w, 0), nz);
+        keep = box_count(occ, wpr, x1, z1, x2, z2, thr) >= thr;
+        mask[i] = (uint8_t)keep;
     }
-    if (kept) atomicAdd(&s_total, kept);
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_total;
+    const int total = __syncthreads_count(keep);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(256)

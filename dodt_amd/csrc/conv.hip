@@ -592,6 +592,9 @@ double layer_bytes(const dodt_extractor* ex, const Layer& l) {
     const double oh = l.deconv ? 2.0 * l.H : l.H, ow = l.deconv ? 2.0 * l.W : l.W;
     double b = ex->batch * ((double)l.H * l.W * l.real_cin * in_e + oh * ow * l.Cout * out_e) +
                9.0 * l.real_cin * l.Cout * w_e;
+    // conv1_1 folded into conv1_2's launch: conv1_1's map is neither written nor read
+    if (ex->first2_variant >= 0 && &l == &ex->layers[0]) b -= ex->batch * oh * ow * l.Cout * out_e;
+    if (ex->first2_variant >= 0 && &l == &ex->layers[1]) b -= ex->batch * (double)l.H * l.W * l.real_cin * in_e;
     if (l.name == "conv1_2" || l.name == "conv2_2" || l.name == "conv3_3")
         b += ex->batch * std::floor(oh / 2) * std::floor(ow / 2) * l.Cout * out_e;
     return b;
@@ -1296,8 +1299,9 @@ int dodt_extractor_forward_timed(dodt_extractor* ex, const float* d_in, float* d
         dodt_layer_info& o = info[i];
         memset(&o, 0, sizeof(o));
         snprintf(o.name, sizeof(o.name), "%s", l.name.c_str());
-        snprintf(o.kernel, sizeof(o.kernel), "%s", kernel_name(variants()[l.main.variant]));
-        o.launches = l.tail.n_items > 0 ? 2 : 1;
+        const bool folded = ex->first2_variant >= 0 && i < 2;      // conv1_1 and conv1_2 are one launch, timed as conv1_2
+        snprintf(o.kernel, sizeof(o.kernel), "%s", kernel_name(variants()[folded ? ex->first2_variant : l.main.variant]));
+        o.launches = folded && i == 0 ? 0 : l.tail.n_items > 0 ? 2 : 1;
         o.items = l.main.n_items + l.tail.n_items;
         o.flops_direct = layer_direct_flops(ex, l);
         o.flops_executed = layer_executed_flops(ex, l);

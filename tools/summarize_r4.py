@@ -18,7 +18,7 @@ import shutil
 import sys
 
 CONV = ('wino43_f32_kernel', 'wino3x3_f32_kernel', 'deconv3x3_dma_kernel', 'deconv3x3_f32_kernel', 'conv3x3_bf16_dma_kernel',
-        'conv3x3_small_cin_kernel', 'conv3x3_mfma_kernel')
+        'conv3x3_small_cin_kernel', 'conv3x3_mfma_kernel', 'conv3x3_bf16_stream_kernel', 'conv3x3_bf16_first2_kernel')
 HBM = {'crop_kernel<4>': 'crop_kernel<4>', 'correlation_sp_kernel': 'correlation_sp_kernel',
        'vox_scatter': 'vox_scatter', 'vox_finalize': 'vox_finalize', 'nms_mask_kernel': 'nms_mask_kernel',
        'nms_scan_kernel': 'nms_scan_kernel'}
