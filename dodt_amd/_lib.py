@@ -137,6 +137,10 @@ SIGNATURES = {
     'dodt_nms': (_i, [_vp, _pf, _pf, _i, _pi32, _i, _f, _pi32, _pi32]),
     'dodt_offset_to_anchor': (_i, [_vp, _pf, _pf, _i, _pi32, _pf]),
     'dodt_softmax_fg': (_i, [_vp, _pf, _i, _pi32, _pf]),
+    'dodt_rpn_decode': (_i, [_vp, _pf, _pf, _pf, _i, _pi32, C.POINTER(_f), _pf, _pf, _pf]),
+    'dodt_gather_project': (_i, [_vp, _pf, _pi32, _i, _pi32, C.POINTER(_f), C.POINTER(_f), _f, _f, _pf, _pf, _pf]),
+    'dodt_final_decode': (_i, [_vp, _pf, _pf, _pf, _pf, _i, _pi32, C.POINTER(_f), C.POINTER(_f),
+                               _pf, _pf, _pf, _pf, _pf, _pf]),
     'dodt_gather_rows': (_i, [_vp, _pf, _i, _pi32, _i, _pi32, _pf]),
     'dodt_max_fg_logit': (_i, [_vp, _pf, _i, _i, _pi32, _pf]),
     'dodt_pack_detections': (_i, [_vp, _pf, _pf, _pf, _pf, _pi32, _pi32, _i, _f, _pf, _pi32]),

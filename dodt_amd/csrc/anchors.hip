@@ -164,15 +164,10 @@ __device__ __forceinline__ void bev_box32(float x, float z, float dx, float dz,
     z2 = (P.z_max - (z - hz)) - P.z_min;
 }
 
-__global__ void __launch_bounds__(256)
-project_f32_kernel(const float* __restrict__ anchors, int n, const int* __restrict__ d_n,
-                   const ProjParams32 P, float* __restrict__ bev, float* __restrict__ bev_norm_tf,
-                   float* __restrict__ img_norm_tf) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lim = d_n ? min(*d_n, n) : n;
-    if (i >= lim) return;
-    const float* a = anchors + (size_t)i * 6;
-    const float x = a[0], y = a[1], z = a[2], dx = a[3], dy = a[4], dz = a[5];
+// one anchor (x, y, z, dx, dy, dz) -> its BEV box in metres / normalised for crop_and_resize / its image box (row i of the outputs)
+__device__ __forceinline__ void project_f32_elem(int i, float x, float y, float z, float dx, float dy, float dz,
+                                                 const ProjParams32& P, float* __restrict__ bev,
+                                                 float* __restrict__ bev_norm_tf, float* __restrict__ img_norm_tf) {
     float x1, z1, x2, z2;
     bev_box32(x, z, dx, dz, P, x1, z1, x2, z2);
     if (bev) {
@@ -207,14 +202,17 @@ project_f32_kernel(const float* __restrict__ anchors, int n, const int* __restri
 }
 
 __global__ void __launch_bounds__(256)
-offset_to_anchor_kernel(const float* __restrict__ anchors, const float* __restrict__ off, int n,
-                        const int* __restrict__ d_n, float* __restrict__ out) {
+project_f32_kernel(const float* __restrict__ anchors, int n, const int* __restrict__ d_n,
+                   const ProjParams32 P, float* __restrict__ bev, float* __restrict__ bev_norm_tf,
+                   float* __restrict__ img_norm_tf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lim = d_n ? min(*d_n, n) : n;
     if (i >= lim) return;
     const float* a = anchors + (size_t)i * 6;
-    const float* t = off + (size_t)i * 6;
-    float* o = out + (size_t)i * 6;
+    project_f32_elem(i, a[0], a[1], a[2], a[3], a[4], a[5], P, bev, bev_norm_tf, img_norm_tf);
+}
+
+__device__ __forceinline__ void offset_to_anchor_elem(const float* __restrict__ a, const float* __restrict__ t, float o[6]) {
     o[0] = (t[0] * a[3]) + a[0];
     o[1] = (t[1] * a[4]) + a[1];
     o[2] = (t[2] * a[5]) + a[2];
@@ -224,15 +222,62 @@ offset_to_anchor_kernel(const float* __restrict__ anchors, const float* __restri
 }
 
 __global__ void __launch_bounds__(256)
+offset_to_anchor_kernel(const float* __restrict__ anchors, const float* __restrict__ off, int n,
+                        const int* __restrict__ d_n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = d_n ? min(*d_n, n) : n;
+    if (i >= lim) return;
+    float o[6];
+    offset_to_anchor_elem(anchors + (size_t)i * 6, off + (size_t)i * 6, o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[(size_t)i * 6 + k] = o[k];
+}
+
+__device__ __forceinline__ float softmax_fg_elem(float l0, float l1) {
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    return e1 / (e0 + e1);
+}
+
+__global__ void __launch_bounds__(256)
 softmax_fg_kernel(const float* __restrict__ logits, int n, const int* __restrict__ d_n,
                   float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lim = d_n ? min(*d_n, n) : n;
     if (i >= lim) return;
-    const float l0 = logits[2 * (size_t)i], l1 = logits[2 * (size_t)i + 1];
-    const float m = fmaxf(l0, l1);
-    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-    out[i] = e1 / (e0 + e1);
+    out[i] = softmax_fg_elem(logits[2 * (size_t)i], logits[2 * (size_t)i + 1]);
+}
+
+// Round 4: the RPN's three elementwise launches in one (offset_to_anchor -> project_to_bev of the regressed anchor ->
+// softmax): the same device functions on the same float values, one launch on a frame's dependent launch chain instead of three.
+__global__ void __launch_bounds__(256)
+rpn_decode_kernel(const float* __restrict__ anchors, const float* __restrict__ off, const float* __restrict__ logits,
+                  int n, const int* __restrict__ d_n, const ProjParams32 P, float* __restrict__ regressed,
+                  float* __restrict__ bev_norm_tf, float* __restrict__ scores) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = d_n ? min(*d_n, n) : n;
+    if (i >= lim) return;
+    float o[6];
+    offset_to_anchor_elem(anchors + (size_t)i * 6, off + (size_t)i * 6, o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) regressed[(size_t)i * 6 + k] = o[k];
+    project_f32_elem(i, o[0], o[1], o[2], o[3], o[4], o[5], P, nullptr, bev_norm_tf, nullptr);
+    scores[i] = softmax_fg_elem(logits[2 * (size_t)i], logits[2 * (size_t)i + 1]);
+}
+
+// ... and the proposals' two: gather the kept rows, project them to both views
+__global__ void __launch_bounds__(256)
+gather_project_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n, const int* __restrict__ d_n,
+                      const ProjParams32 P, float* __restrict__ rows, float* __restrict__ bev_norm_tf,
+                      float* __restrict__ img_norm_tf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = d_n ? min(*d_n, n) : n;
+    if (i >= lim) return;
+    const float* a = src + (size_t)idx[i] * 6;
+    float o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { o[k] = a[k]; rows[(size_t)i * 6 + k] = o[k]; }
+    project_f32_elem(i, o[0], o[1], o[2], o[3], o[4], o[5], P, nullptr, bev_norm_tf, img_norm_tf);
 }
 
 __global__ void __launch_bounds__(256)
@@ -351,14 +396,10 @@ struct DecodeParams {
     float x_min, x_max, z_min, z_max;
 };
 
-__global__ void __launch_bounds__(256)
-box_4c_decode_kernel(const float* __restrict__ top_anchors, const float* __restrict__ offsets,
-                     int n, const int* __restrict__ d_n, const DecodeParams P,
-                     float* __restrict__ boxes_3d, float* __restrict__ pred_anchors,
-                     float* __restrict__ bev_tf) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lim = d_n ? min(*d_n, n) : n;
-    if (i >= lim) return;
+__device__ __forceinline__ void box_4c_decode_elem(int i, const float* __restrict__ top_anchors,
+                                                   const float* __restrict__ offsets, const DecodeParams& P,
+                                                   float* __restrict__ boxes_3d, float* __restrict__ pred_anchors,
+                                                   float* __restrict__ bev_tf) {
     const float* a = top_anchors + (size_t)i * 6;
     const float half_pi = (float)(M_PI / 2);
     // anchors_to_box_3d(fix_lw=True), tensor branch (box_3d_encoder.py:249-290)
@@ -421,6 +462,35 @@ box_4c_decode_kernel(const float* __restrict__ top_anchors, const float* __restr
         float* o = bev_tf + (size_t)i * 4;
         o[0] = z1; o[1] = x1; o[2] = z2; o[3] = x2;
     }
+}
+
+__global__ void __launch_bounds__(256)
+box_4c_decode_kernel(const float* __restrict__ top_anchors, const float* __restrict__ offsets,
+                     int n, const int* __restrict__ d_n, const DecodeParams P,
+                     float* __restrict__ boxes_3d, float* __restrict__ pred_anchors,
+                     float* __restrict__ bev_tf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = d_n ? min(*d_n, n) : n;
+    if (i >= lim) return;
+    box_4c_decode_elem(i, top_anchors, offsets, P, boxes_3d, pred_anchors, bev_tf);
+}
+
+// Round 4: what follows the stage-2 head per proposal in one launch: box_4c decode, the NMS score (largest foreground
+// logit), the record score (softmax) and the orientation of the angle vector -- four launches of a frame's chain before
+__global__ void __launch_bounds__(256)
+final_decode_kernel(const float* __restrict__ top_anchors, const float* __restrict__ offsets,
+                    const float* __restrict__ cls_logits, const float* __restrict__ angle_vec, int n,
+                    const int* __restrict__ d_n, const DecodeParams P, float* __restrict__ boxes_3d,
+                    float* __restrict__ pred_anchors, float* __restrict__ bev_tf, float* __restrict__ nms_scores,
+                    float* __restrict__ det_scores, float* __restrict__ orientations) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = d_n ? min(*d_n, n) : n;
+    if (i >= lim) return;
+    box_4c_decode_elem(i, top_anchors, offsets, P, boxes_3d, pred_anchors, bev_tf);
+    const float l0 = cls_logits[2 * (size_t)i], l1 = cls_logits[2 * (size_t)i + 1];
+    nms_scores[i] = l1;                                  // max over the one foreground class
+    det_scores[i] = softmax_fg_elem(l0, l1);
+    if (orientations) orientations[i] = atan2f(angle_vec[2 * i + 1], angle_vec[2 * i]);
 }
 
 }  // namespace
@@ -487,6 +557,58 @@ int dodt_project_anchors_f32(dodt_ctx* ctx, const float* d_anchors, int n, const
     hipLaunchKernelGGL(project_f32_kernel, dim3(dodt::ceil_div(n, 256)), dim3(256), 0,
                        ctx->stream, d_anchors, n, d_n, P, d_bev_out, d_bev_norm_tf_out,
                        d_img_norm_tf_out);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int dodt_rpn_decode(dodt_ctx* ctx, const float* d_anchors, const float* d_offsets, const float* d_logits2, int n,
+                    const int32_t* d_n, const float bev_extents[4], float* d_regressed_out,
+                    float* d_bev_norm_tf_out, float* d_scores_out) {
+    DODT_REQUIRE(ctx && d_anchors && d_offsets && d_logits2 && bev_extents && d_regressed_out && d_bev_norm_tf_out &&
+                     d_scores_out, "dodt_rpn_decode: NULL argument");
+    if (n <= 0) return DODT_OK;
+    ProjParams32 P = {};
+    P.x_min = bev_extents[0]; P.x_max = bev_extents[1];
+    P.z_min = bev_extents[2]; P.z_max = bev_extents[3];
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(dodt::ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_anchors,
+                       d_offsets, d_logits2, n, d_n, P, d_regressed_out, d_bev_norm_tf_out, d_scores_out);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int dodt_gather_project(dodt_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, const int32_t* d_n,
+                        const float bev_extents[4], const float p2[12], float im_w, float im_h,
+                        float* d_rows_out, float* d_bev_norm_tf_out, float* d_img_norm_tf_out) {
+    DODT_REQUIRE(ctx && d_src && d_idx && bev_extents && p2 && d_rows_out && d_bev_norm_tf_out && d_img_norm_tf_out,
+                 "dodt_gather_project: NULL argument");
+    if (n <= 0) return DODT_OK;
+    ProjParams32 P;
+    P.x_min = bev_extents[0]; P.x_max = bev_extents[1];
+    P.z_min = bev_extents[2]; P.z_max = bev_extents[3];
+    for (int k = 0; k < 12; ++k) P.p[k] = p2[k];
+    P.im_w = im_w; P.im_h = im_h;
+    hipLaunchKernelGGL(gather_project_kernel, dim3(dodt::ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_src, d_idx,
+                       n, d_n, P, d_rows_out, d_bev_norm_tf_out, d_img_norm_tf_out);
+    DODT_LAUNCH_CHECK();
+    return DODT_OK;
+}
+
+int dodt_final_decode(dodt_ctx* ctx, const float* d_top_anchors, const float* d_offsets, const float* d_cls_logits2,
+                      const float* d_angle_vectors, int n, const int32_t* d_n, const float plane[4],
+                      const float bev_extents[4], float* d_boxes_3d_out, float* d_pred_anchors_out,
+                      float* d_bev_tf_out, float* d_nms_scores_out, float* d_det_scores_out,
+                      float* d_orientations_out) {
+    DODT_REQUIRE(ctx && d_top_anchors && d_offsets && d_cls_logits2 && plane && bev_extents && d_nms_scores_out &&
+                     d_det_scores_out && (d_angle_vectors != nullptr) == (d_orientations_out != nullptr),
+                 "dodt_final_decode: bad argument");
+    if (n <= 0) return DODT_OK;
+    DecodeParams P;
+    P.a = plane[0]; P.b = plane[1]; P.c = plane[2]; P.d = plane[3];
+    P.x_min = bev_extents[0]; P.x_max = bev_extents[1];
+    P.z_min = bev_extents[2]; P.z_max = bev_extents[3];
+    hipLaunchKernelGGL(final_decode_kernel, dim3(dodt::ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_top_anchors,
+                       d_offsets, d_cls_logits2, d_angle_vectors, n, d_n, P, d_boxes_3d_out, d_pred_anchors_out,
+                       d_bev_tf_out, d_nms_scores_out, d_det_scores_out, d_orientations_out);
     DODT_LAUNCH_CHECK();
     return DODT_OK;
 }

@@ -130,6 +130,29 @@ def softmax_fg(ctx, d_logits, n, d_n, d_scores):
         ctx.handle, _p(d_logits), int(n), _p(d_n), _p(d_scores)), 'dodt_softmax_fg')
 
 
+def rpn_decode(ctx, d_anchors, d_offsets, d_logits, n, d_n, bev_extents, d_regressed, d_bev_norm_tf, d_scores):
+    """offset_to_anchor + project_anchors_f32 (normalised BEV boxes) + softmax_fg in one launch."""
+    _lib.check(ctx.lib.dodt_rpn_decode(
+        ctx.handle, _p(d_anchors), _p(d_offsets), _p(d_logits), int(n), _p(d_n), _arr(C.c_float, bev_extents),
+        _p(d_regressed), _p(d_bev_norm_tf), _p(d_scores)), 'dodt_rpn_decode')
+
+
+def gather_project(ctx, d_src, d_idx, n, d_n, bev_extents, p2, im_wh, d_rows, d_bev_norm_tf, d_img_norm_tf):
+    """gather_rows (width 6) + project_anchors_f32 (both views) in one launch."""
+    _lib.check(ctx.lib.dodt_gather_project(
+        ctx.handle, _p(d_src), _p(d_idx), int(n), _p(d_n), _arr(C.c_float, bev_extents), _arr(C.c_float, p2),
+        float(im_wh[0]), float(im_wh[1]), _p(d_rows), _p(d_bev_norm_tf), _p(d_img_norm_tf)), 'dodt_gather_project')
+
+
+def final_decode(ctx, d_top_anchors, d_offsets, d_cls_logits, d_angle_vectors, n, d_n, plane, bev_extents,
+                 d_boxes_3d, d_pred_anchors, d_bev_tf, d_nms_scores, d_det_scores, d_orientations):
+    """box_4c_decode + max_fg_logit + softmax_fg [+ angle_vector_to_orientation] in one launch."""
+    _lib.check(ctx.lib.dodt_final_decode(
+        ctx.handle, _p(d_top_anchors), _p(d_offsets), _p(d_cls_logits), _p(d_angle_vectors), int(n), _p(d_n),
+        _arr(C.c_float, plane), _arr(C.c_float, bev_extents), _p(d_boxes_3d), _p(d_pred_anchors), _p(d_bev_tf),
+        _p(d_nms_scores), _p(d_det_scores), _p(d_orientations)), 'dodt_final_decode')
+
+
 def gather_rows(ctx, d_src, width, d_idx, n, d_n, d_out):
     _lib.check(ctx.lib.dodt_gather_rows(
         ctx.handle, _p(d_src), int(width), _p(d_idx), int(n), _p(d_n), _p(d_out)),

@@ -517,6 +517,7 @@ class FramePairPipeline(object):
         split_t = computed and self.fps == 2 and ns >= 2 and not os.environ.get('DODT_PIPE_NO_CORR') \
             and os.environ.get('DODT_PIPE_CORR_ON_F1', '1') != '0'
         corr_img = split_t and self._corr_on_img()
+        fused_tail = os.environ.get('DODT_PIPE_FUSED_TAIL', '1') != '0'
 
         def t_branch_crops(cc, f0, scratch):
             """Correlation map of pair (f0, f0 + 1) and its 7x7 crops at frame f0's proposals, on context cc."""
@@ -548,19 +549,31 @@ class FramePairPipeline(object):
                                       b['rpn_offsets'], scratch['rpn'])
             self._mark(c, st['step'], 'tail%d_rpn' % f)
             # -- a12, a5, a13: decode, project, NMS #1 --------------------------------------
-            ops.offset_to_anchor(c, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
-            ops.project_anchors_f32(c, b['regressed'], A, None, self.bev_extents_flat, self.p2,
-                                    self.image_wh, d_bev_norm_tf=b['prop_bev'])
-            ops.softmax_fg(c, h['rpn_logits'], A, None, b['scores'])
+            # (round 4: the elementwise runs of a frame's launch chain are one launch each -- rpn_decode, gather_project,
+            #  final_decode below: the same arithmetic value for value, six launches fewer per frame;
+            #  DODT_PIPE_FUSED_TAIL=0: the separate ops)
+            if fused_tail:
+                ops.rpn_decode(c, b['anchors'], h['rpn_offsets'], h['rpn_logits'], A, None, self.bev_extents_flat,
+                               b['regressed'], b['prop_bev'], b['scores'])
+            else:
+                ops.offset_to_anchor(c, b['anchors'], h['rpn_offsets'], A, None, b['regressed'])
+                ops.project_anchors_f32(c, b['regressed'], A, None, self.bev_extents_flat, self.p2,
+                                        self.image_wh, d_bev_norm_tf=b['prop_bev'])
+                ops.softmax_fg(c, h['rpn_logits'], A, None, b['scores'])
             ops.nms(c, b['prop_bev'], b['scores'], A, None, self.P,
                     cfg['rpn_nms_iou_thresh'], b['top_idx'], b['top_count'])
-            ops.gather_rows(c, b['regressed'], 6, b['top_idx'], self.P, b['top_count'],
-                            b['top_anchors'])
-            self._mark(c, st['step'], 'tail%d_nms1' % f)
-            # -- stage 2: project proposals, 7x7 crops --------------------------------------
-            ops.project_anchors_f32(c, b['top_anchors'], self.P, b['top_count'],
-                                    self.bev_extents_flat, self.p2, self.image_wh,
-                                    d_bev_norm_tf=b['top_bev'], d_img_norm_tf=b['top_img'])
+            if fused_tail:
+                # -- stage 2: the kept proposals and their projections, 7x7 crops ---------------
+                ops.gather_project(c, b['regressed'], b['top_idx'], self.P, b['top_count'], self.bev_extents_flat,
+                                   self.p2, self.image_wh, b['top_anchors'], b['top_bev'], b['top_img'])
+                self._mark(c, st['step'], 'tail%d_nms1' % f)
+            else:
+                ops.gather_rows(c, b['regressed'], 6, b['top_idx'], self.P, b['top_count'],
+                                b['top_anchors'])
+                self._mark(c, st['step'], 'tail%d_nms1' % f)
+                ops.project_anchors_f32(c, b['top_anchors'], self.P, b['top_count'],
+                                        self.bev_extents_flat, self.p2, self.image_wh,
+                                        d_bev_norm_tf=b['top_bev'], d_img_norm_tf=b['top_img'])
             ops.crop_and_resize(c, feat_b, bev_hw + (FC,), b['top_bev'], self.P,
                                 b['top_count'], (ROI, ROI), b['bev_rois'])
             ops.crop_and_resize(c, feat_i, img_hw + (FC,), b['top_img'], self.P,
@@ -591,20 +604,28 @@ class FramePairPipeline(object):
                                                [b['corr_offsets']], scratch['fc'])
             self._mark(c, st['step'], 'tail%d_heads' % f)
             # -- a14, a13: box_4c decode, NMS #2 ---------------------------------------------
-            ops.box_4c_decode(c, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
-                              plane, self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'],
-                              b['nms2_boxes'])
-            ops.max_fg_logit(c, h['cls_logits'], 2, self.P, b['top_count'], b['nms2_scores'])
-            ops.nms(c, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
-                    cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
             # record score = softmax over [background, class] (dt_evaluator.py:1226-1248)
-            ops.softmax_fg(c, h['cls_logits'], self.P, b['top_count'], b['det_scores'])
             # box_4ca: all_orientations = atan2 of the angle vectors (dt_avod_model.py:547-548),
             # gathered with the boxes by NMS #2's indices (:631-634) inside the record kernel,
             # which applies the evaluator's heading correction (dt_evaluator.py:1166-1212)
-            if self.box_4ca:
-                ops.angle_vector_to_orientation(c, h['angle_vectors'], self.P, b['top_count'],
-                                                b['orientations'])
+            if fused_tail:
+                ops.final_decode(c, b['top_anchors'], h['offsets_4c'], h['cls_logits'],
+                                 h['angle_vectors'] if self.box_4ca else None, self.P, b['top_count'], plane,
+                                 self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'], b['nms2_boxes'],
+                                 b['nms2_scores'], b['det_scores'], b['orientations'] if self.box_4ca else None)
+                ops.nms(c, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
+                        cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
+            else:
+                ops.box_4c_decode(c, b['top_anchors'], h['offsets_4c'], self.P, b['top_count'],
+                                  plane, self.bev_extents_flat, b['boxes_3d'], b['pred_anchors'],
+                                  b['nms2_boxes'])
+                ops.max_fg_logit(c, h['cls_logits'], 2, self.P, b['top_count'], b['nms2_scores'])
+                ops.nms(c, b['nms2_boxes'], b['nms2_scores'], self.P, b['top_count'], MAX_DET,
+                        cfg['avod_nms_iou_thresh'], b['det_idx'], b['det_count'])
+                ops.softmax_fg(c, h['cls_logits'], self.P, b['top_count'], b['det_scores'])
+                if self.box_4ca:
+                    ops.angle_vector_to_orientation(c, h['angle_vectors'], self.P, b['top_count'],
+                                                    b['orientations'])
             yield 'pack'
             ops.pack_detections(
                 c, b['boxes_3d'], b['det_scores'], b['det_idx'], b['det_count'], MAX_DET,

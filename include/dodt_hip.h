@@ -394,6 +394,25 @@ int dodt_offset_to_anchor(dodt_ctx* ctx, const float* d_anchors, const float* d_
 /* 2-way softmax, column 1 (models/dt_rpn_model.py:581-584) */
 int dodt_softmax_fg(dodt_ctx* ctx, const float* d_logits2, int n, const int32_t* d_n,
                     float* d_scores_out);
+/* One launch for the three elementwise steps between the RPN head and NMS #1 (models/dt_rpn_model.py:560-591):
+ * dodt_offset_to_anchor (-> d_regressed_out (n,6)), dodt_project_anchors_f32's normalised BEV boxes of the regressed anchors
+ * (-> d_bev_norm_tf_out (n,4)) and dodt_softmax_fg (-> d_scores_out (n)) -- the same arithmetic, value for value. */
+int dodt_rpn_decode(dodt_ctx* ctx, const float* d_anchors, const float* d_offsets, const float* d_logits2, int n,
+                    const int32_t* d_n, const float bev_extents[4], float* d_regressed_out,
+                    float* d_bev_norm_tf_out, float* d_scores_out);
+/* ... for the two behind NMS #1 (models/dt_rpn_model.py:593-612, dt_avod_model.py:176-200): dodt_gather_rows of the kept
+ * proposals (width 6 -> d_rows_out (n,6)) and their dodt_project_anchors_f32 boxes in both views. */
+int dodt_gather_project(dodt_ctx* ctx, const float* d_src, const int32_t* d_idx, int n, const int32_t* d_n,
+                        const float bev_extents[4], const float p2[12], float im_w, float im_h,
+                        float* d_rows_out, float* d_bev_norm_tf_out, float* d_img_norm_tf_out);
+/* ... and for the four behind the stage-2 head (models/dt_avod_model.py:520-548,600-634): dodt_box_4c_decode,
+ * dodt_max_fg_logit of the two-class logits (-> d_nms_scores_out), dodt_softmax_fg (-> d_det_scores_out) and, with
+ * d_angle_vectors, dodt_angle_vector_to_orientation (-> d_orientations_out; both NULL for box_4c). */
+int dodt_final_decode(dodt_ctx* ctx, const float* d_top_anchors, const float* d_offsets, const float* d_cls_logits2,
+                      const float* d_angle_vectors, int n, const int32_t* d_n, const float plane[4],
+                      const float bev_extents[4], float* d_boxes_3d_out, float* d_pred_anchors_out,
+                      float* d_bev_tf_out, float* d_nms_scores_out, float* d_det_scores_out,
+                      float* d_orientations_out);
 /* out[i] = src[idx[i]] rows of `width` floats (tf.gather call sites
  * dt_rpn_model.py:593-597, dt_avod_model.py:616-640) */
 int dodt_gather_rows(dodt_ctx* ctx, const float* d_src, int width, const int32_t* d_idx,

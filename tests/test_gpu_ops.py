@@ -261,3 +261,65 @@ def test_mean_fusion_is_the_float32_mean(ctx):
     assert np.array_equal(d_out.download(), oheads.mean_fusion(a, b))
     with pytest.raises(ValueError):
         ops.mean_fusion(ctx, ctx.array(a), ctx.array(b), 333, None, 1567, d_out)
+
+
+@pytest.mark.parametrize('n,n_valid', [(5000, None), (1024, 700), (1, None), (257, 0)])
+def test_fused_tail_ops_equal_the_separate_ops_bit_for_bit(ctx, n, n_valid):
+    """dodt_rpn_decode, dodt_gather_project and dodt_final_decode (round 4: one launch for each elementwise run of a frame's
+    launch chain) against the ops they replace -- which the tests above hold to the oracle and the reference's goldens --
+    on the same inputs: every output array equal bit for bit, rows beyond *d_n untouched."""
+    rng = np.random.default_rng(n * 7 + (n_valid or 0))
+    ae = np.asarray(C['area_extents'], np.float32)
+    ext = [float(ae[0, 0]), float(ae[0, 1]), float(ae[2, 0]), float(ae[2, 1])]
+    p2 = rng.normal(0, 1, 12).astype(np.float32) * np.asarray([700, 1, 600, 40, 1, 700, 180, 2, 0.01, 0.01, 1, 0.003], np.float32)
+    plane = [0.0, -1.0, 0.0, 1.65]
+    d_n = ctx.array(np.asarray([n_valid], np.int32)) if n_valid is not None else None
+    anchors = np.concatenate([rng.uniform(-40, 40, (n, 1)), rng.uniform(0.5, 2, (n, 1)), rng.uniform(0, 70, (n, 1)),
+                              rng.uniform(1, 5, (n, 3))], 1).astype(np.float32)
+    offs = rng.normal(0, 0.3, (n, 6)).astype(np.float32)
+    logits = rng.normal(0, 3, (n, 2)).astype(np.float32)
+    d_a, d_o, d_l = ctx.array(anchors), ctx.array(offs), ctx.array(logits)
+
+    def fresh(*shape):
+        return ctx.array(np.full(shape, -7.0, np.float32))
+
+    # --- RPN run
+    reg0, bev0, sc0 = fresh(n, 6), fresh(n, 4), fresh(n)
+    ops.offset_to_anchor(ctx, d_a, d_o, n, d_n, reg0)
+    ops.project_anchors_f32(ctx, reg0, n, d_n, ext, p2, (1242.0, 375.0), d_bev_norm_tf=bev0)
+    ops.softmax_fg(ctx, d_l, n, d_n, sc0)
+    reg1, bev1, sc1 = fresh(n, 6), fresh(n, 4), fresh(n)
+    ops.rpn_decode(ctx, d_a, d_o, d_l, n, d_n, ext, reg1, bev1, sc1)
+    for a0, a1 in ((reg0, reg1), (bev0, bev1), (sc0, sc1)):
+        assert np.array_equal(a0.download(), a1.download(), equal_nan=True)
+    # --- the proposals' run
+    m = max(1, n // 3)
+    idx = rng.integers(0, n, m).astype(np.int32)
+    d_idx = ctx.array(idx)
+    d_m = ctx.array(np.asarray([min(m, n_valid)], np.int32)) if n_valid is not None else None
+    rows0, tb0, ti0 = fresh(m, 6), fresh(m, 4), fresh(m, 4)
+    ops.gather_rows(ctx, reg0, 6, d_idx, m, d_m, rows0)
+    ops.project_anchors_f32(ctx, rows0, m, d_m, ext, p2, (1242.0, 375.0), d_bev_norm_tf=tb0, d_img_norm_tf=ti0)
+    rows1, tb1, ti1 = fresh(m, 6), fresh(m, 4), fresh(m, 4)
+    ops.gather_project(ctx, reg0, d_idx, m, d_m, ext, p2, (1242.0, 375.0), rows1, tb1, ti1)
+    for a0, a1 in ((rows0, rows1), (tb0, tb1), (ti0, ti1)):
+        assert np.array_equal(a0.download(), a1.download(), equal_nan=True)
+    # --- behind the stage-2 head
+    off4c = rng.normal(0, 0.2, (m, 10)).astype(np.float32)
+    cls = rng.normal(0, 3, (m, 2)).astype(np.float32)
+    ang = rng.normal(0, 1, (m, 2)).astype(np.float32)
+    d_off, d_cls, d_ang = ctx.array(off4c), ctx.array(cls), ctx.array(ang)
+    for with_angle in (True, False):
+        b0, pa0, bt0, ns0, ds0, or0 = fresh(m, 7), fresh(m, 6), fresh(m, 4), fresh(m), fresh(m), fresh(m)
+        ops.box_4c_decode(ctx, rows0, d_off, m, d_m, plane, ext, b0, pa0, bt0)
+        ops.max_fg_logit(ctx, d_cls, 2, m, d_m, ns0)
+        ops.softmax_fg(ctx, d_cls, m, d_m, ds0)
+        if with_angle:
+            ops.angle_vector_to_orientation(ctx, d_ang, m, d_m, or0)
+        b1, pa1, bt1, ns1, ds1, or1 = fresh(m, 7), fresh(m, 6), fresh(m, 4), fresh(m), fresh(m), fresh(m)
+        ops.final_decode(ctx, rows0, d_off, d_cls, d_ang if with_angle else None, m, d_m, plane, ext, b1, pa1, bt1,
+                         ns1, ds1, or1 if with_angle else None)
+        for a0, a1 in ((b0, b1), (pa0, pa1), (bt0, bt1), (ns0, ns1), (ds0, ds1), (or0, or1)):
+            assert np.array_equal(a0.download(), a1.download(), equal_nan=True)
+    with pytest.raises(ValueError):
+        ops.final_decode(ctx, rows0, d_off, d_cls, d_ang, m, d_m, plane, ext, b1, pa1, bt1, ns1, ds1, None)
