@@ -34,7 +34,10 @@ __device__ __forceinline__ int box_count(const uint32_t* __restrict__ occ, int w
     return cnt;
 }
 
-__global__ void __launch_bounds__(256)
+// (64-lane workgroups since round 4: a lane walks up to 43 rows x 3 words of L2-resident bits one after the other, and 350
+//  workgroups of 256 gave a CU one or two of those latency chains to overlap; block_counts is per 64 anchors)
+constexpr int kMaskBlock = 64;
+__global__ void __launch_bounds__(kMaskBlock)
 anchor_mask_kernel(const uint32_t* __restrict__ occ, int wpr, int nx, int nz,
                    const int4* __restrict__ cells, int n, int thr,
                    uint8_t* __restrict__ mask, int* __restrict__ block_counts) {
@@ -48,7 +51,7 @@ anchor_mask_kernel(const uint32_t* __restrict__ occ, int wpr, int nx, int nz,
         keep = box_count(occ, wpr, x1, z1, x2, z2, thr) >= thr;
         mask[i] = (uint8_t)keep;
     }
-    const int total = __syncthreads_count(keep);
+    const int total = __popcll(__ballot(keep));      // one wave per workgroup
     if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
@@ -58,9 +61,9 @@ anchor_compact_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ 
     __shared__ int s_part[256];
     __shared__ int s_wave[4];
     const int tid = threadIdx.x;
-    // offset of this block = sum of the counts of the blocks before it
+    // offset of this block = sum of the counts of the (64-anchor) mask blocks before it
     int part = 0;
-    for (int j = tid; j < (int)blockIdx.x; j += 256) part += block_counts[j];
+    for (int j = tid; j < (int)blockIdx.x * (256 / kMaskBlock); j += 256) part += block_counts[j];
     s_part[tid] = part;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -507,13 +510,13 @@ int dodt_anchor_filter(dodt_ctx* ctx, const uint32_t* d_occ_bits, int nx, int nz
         DODT_HIP_CHECK(hipMemsetAsync(d_count_out, 0, sizeof(int32_t), ctx->stream));
         return DODT_OK;
     }
-    const int blocks = dodt::ceil_div(n_anchors, 256);
+    const int blocks = dodt::ceil_div(n_anchors, 256), mask_blocks = dodt::ceil_div(n_anchors, kMaskBlock);
     const size_t mask_bytes = dodt::align_up((size_t)n_anchors, 256);
-    int rc = ctx->anchor_ws.reserve(mask_bytes + (size_t)blocks * sizeof(int));
+    int rc = ctx->anchor_ws.reserve(mask_bytes + (size_t)mask_blocks * sizeof(int));
     if (rc) return rc;
     uint8_t* mask = reinterpret_cast<uint8_t*>(ctx->anchor_ws.ptr);
     int* block_counts = reinterpret_cast<int*>(mask + mask_bytes);
-    hipLaunchKernelGGL(anchor_mask_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_occ_bits,
+    hipLaunchKernelGGL(anchor_mask_kernel, dim3(mask_blocks), dim3(kMaskBlock), 0, ctx->stream, d_occ_bits,
                        dodt::ceil_div(nx, 32), nx, nz,
                        reinterpret_cast<const int4*>(d_anchor_cells), n_anchors,
                        density_threshold, mask, block_counts);

@@ -24,8 +24,8 @@ VARIANTS = [
     ({'DODT_CONV_BF16_MT2': '0'}, ['tests/test_gpu_conv_bf16.py']),
     ({'DODT_CONV_BF16_XCD': '0', 'DODT_CONV_F32_XCD': '0'},
      ['tests/test_gpu_conv_bf16.py', 'tests/test_gpu_conv.py', '-k', 'not other_fp32']),
-    # the streaming bf16 kernels with their shallowest rings (the default takes the deepest that fits twice per CU)
-    ({'DODT_CONV_BF16_STREAM_LDS': '40'}, ['tests/test_gpu_conv_bf16.py', '-k', 'all_layers']),
+    # the streaming bf16 kernels with shallower rings (the default takes the deepest that fits twice per CU)
+    ({'DODT_CONV_BF16_STREAM_LDS': '72'}, ['tests/test_gpu_conv_bf16.py', '-k', 'all_layers']),
     # the tail's elementwise ops as separate launches; the correlation map inside frame 1's tail (round 4's first form)
     ({'DODT_PIPE_FUSED_TAIL': '0', 'DODT_PIPE_CORR_MAP': 'f1'},
      ['tests/test_gpu_heads.py', 'tests/test_gpu_pipeline.py', '-k', 'stagewise or lookahead or pipelined']),
