@@ -117,3 +117,29 @@ def test_bf16_extractor_oracle_stays_close_to_fp32():
     b16 = oext.vgg_pyramid(x, p, pad_top=4, conv_dtype='bf16')
     rel = np.abs(f32 - b16).max() / np.abs(f32).max()
     assert 0 < rel < 3e-2
+
+
+def test_split_first_layer_restatement_is_fp32_grade():
+    """first_layer='split' (the device's folded conv1_1: x and w as hi + lo bf16 pairs, three products per term) against the
+    fp32 first layer of the same bf16 restatement: the stored bf16 conv1_1 maps agree except where a 2^-17 difference flips
+    a rounding -- a few elements per thousand, by one bf16 ulp --, and the network outputs stay as close to fp32."""
+    from dodt_amd import synth
+    from oracle import extractors as oext
+    from oracle import tfops
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 60, size=(24, 40, 3)).astype(np.float32)
+    p = synth.pyramid_params(3, 142)
+    ca, cb = {}, {}
+    fa = oext.vgg_pyramid(x, p, collect=ca, conv_dtype='bf16')
+    fb = oext.vgg_pyramid(x, p, collect=cb, conv_dtype='bf16', first_layer='split')
+    a, b = ca['conv1_1'], cb['conv1_1']
+    assert np.array_equal(b, tfops.round_bf16(b))
+    differ = a != b
+    assert differ.mean() < 0.02
+    # one ulp of an 8-bit mantissa (or, next to the ReLU's zero, the 2^-17 difference itself)
+    assert np.all(np.abs(a - b)[differ] <= np.maximum(np.abs(a), np.abs(b))[differ] * 2.0 ** -7 + 1e-4 * np.abs(a).max())
+    f32 = oext.vgg_pyramid(x, p)
+    scale = np.abs(f32).max()
+    assert np.abs(fb - f32).max() / scale < 3e-2 and np.abs(fa - fb).max() / scale < 3e-2
+    # fp32 path: the option changes nothing
+    assert np.array_equal(oext.vgg_pyramid(x, p, first_layer='split'), f32)
