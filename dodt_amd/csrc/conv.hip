@@ -169,7 +169,7 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
                 if (vs[i].stream_nch > 0 && vs[i].stream_nch * 16 == Cin && vs[i].lds_bytes <= stream_lds) return (int)i;
         long best_n = 0;
         static const long per_cu = getenv("DODT_CONV_BF16_ITEMS_PER_CU") ? atol(getenv("DODT_CONV_BF16_ITEMS_PER_CU")) : 4;
-        // 8-row tiles (three workgroups per CU) only where the 16-row tiles give fewer than 1.6 items per CU -- the
+        // 8-row tiles (three workgroups per CU): first only where the 16-row tiles gave fewer than 1.6 items per CU -- the
         // 88 x 100 / 45 x 150 maps of the deepest level: conv4_2 34 -> 30 us, stacks 1.065 -> 1.043 ms alone, nothing in
         // the pipeline; at 1.9 items per CU (the image net's level 3, 480 items) they are slower: 26 -> 29 us
         // (DODT_CONV_BF16_MT2=0: never; DODT_CONV_BF16_MT2_BELOW=<items>: another threshold)
@@ -179,7 +179,20 @@ int pick_variant(bool deconv, int H, int W, int Cin, int Cout, bool bf16, int pa
         for (size_t i = 0; i < vs.size(); ++i)
             if (vs[i].dma && !vs[i].stream_nch && !vs[i].first2 && vs[i].TH == 16 && Cout % vs[i].BN == 0)
                 n16 = std::max(n16, (long)dodt::ceil_div(H, 16) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch);
-        const bool want_mt2 = mt2 && n16 < (mt2_below > 0 ? mt2_below : 8L * num_cus / 5);
+        // Round 4, late (the epilogue's cost per item fell), measured and NOT the default: a round model instead of the item
+        // threshold (DODT_CONV_BF16_MT2_RULE=rounds) -- 16-row tiles take ceil(items / 2 per CU) rounds of an item time, 8-row
+        // tiles ceil(items / 3 per CU) rounds of 0.625 of it; 8-row tiles where that is a tenth shorter.  It adds the BEV net's
+        // level-2 / level-3 layers (1 144 and 616 items on 512 slots: a mostly empty last round): conv2_2 35 -> 30, conv3_2
+        // 33 -> 28, conv3_3 35 -> 29 us, both stacks 0.875 -> 0.849 ms ALONE -- but 0.695 -> 0.71 ms side by side (three
+        // workgroups per CU leave the other stack's kernels less room) and 1 013-1 027 -> 1 009 pairs/s in the pipeline.
+        static const bool rounds_rule = getenv("DODT_CONV_BF16_MT2_RULE") && !strcmp(getenv("DODT_CONV_BF16_MT2_RULE"), "rounds");
+        long n8 = 0;
+        for (size_t i = 0; i < vs.size(); ++i)
+            if (vs[i].dma && !vs[i].stream_nch && !vs[i].first2 && vs[i].TH == 8 && Cout % vs[i].BN == 0)
+                n8 = std::max(n8, (long)dodt::ceil_div(H, 8) * dodt::ceil_div(W, vs[i].TW) * (Cout / vs[i].BN) * batch);
+        const double t16 = (double)dodt::ceil_div((int)n16, 2 * num_cus), t8 = 0.625 * dodt::ceil_div((int)n8, 3 * num_cus);
+        const bool want_mt2 = mt2 && n8 > 0 && (rounds_rule ? t8 < 0.9 * t16
+                                                            : n16 < (mt2_below > 0 ? mt2_below : 8L * num_cus / 5));
         for (size_t i = 0; i < vs.size(); ++i) {
             if (!vs[i].dma || vs[i].stream_nch || vs[i].first2 || Cout % vs[i].BN != 0) continue;
             if ((vs[i].TH == 8) != want_mt2) continue;

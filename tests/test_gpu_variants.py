@@ -22,6 +22,7 @@ VARIANTS = [
     # bf16 convs: 16-row tiles also where the map gives fewer than 1.6 items per CU (the small test maps otherwise
     # all take the 8-row tiles)
     ({'DODT_CONV_BF16_MT2': '0'}, ['tests/test_gpu_conv_bf16.py']),
+    ({'DODT_CONV_BF16_MT2_RULE': 'rounds'}, ['tests/test_gpu_conv_bf16.py', '-k', 'all_layers']),
     ({'DODT_CONV_BF16_XCD': '0', 'DODT_CONV_F32_XCD': '0'},
      ['tests/test_gpu_conv_bf16.py', 'tests/test_gpu_conv.py', '-k', 'not other_fp32']),
     # the streaming bf16 kernels with shallower rings (the default takes the deepest that fits twice per CU)
