@@ -550,3 +550,44 @@ def test_pair_free_running_by_conv_mode(tmp_path):
     # the rule of DESIGN.md 5.0, on the pooled fractions
     assert table[default_mode]['exact_pooled'][1] >= table['direct']['exact_pooled'][1] - 0.10, \
         (default_mode, table[default_mode]['exact_pooled'], table['direct']['exact_pooled'])
+
+
+@pytest.mark.parametrize('conv_dtype,head_dtype', [('f32', 'f32'), ('bf16', 'bf16')])
+def test_two_pairs_per_step_with_computed_heads_match_single_pair_steps(ctx, conv_dtype, head_dtype):
+    """The whole S+T graph with two pairs per step (what `alt.batched` times): the correlation maps of both pairs behind
+    the image stack, their crops and heads on the pairs' second frames' streams, look-ahead prep, three steps deep -- the
+    records of every pair equal, bit for bit, those of a one-pair pipeline run on that pair alone."""
+    hp = synth.head_params()
+    kw = dict(rpn_nms_size=1024, head_params=hp, conv_dtype=conv_dtype, head_dtype=head_dtype)
+    pipe2 = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), pairs_per_step=2, **kw)
+    pipe1 = FramePairPipeline(ctx, C, **synth.pipeline_weights(C), reuse_streams_of=pipe2, **kw)
+    steps = [[(3, 0), (3, 2), (5, 1), (5, 3)], [(4, 0), (4, 2), (6, 1), (6, 3)], [(3, 4), (3, 6), (5, 5), (5, 7)]]
+    ins = []
+    for frames in steps:
+        pts = [synth.lidar_frame(s, f) for s, f in frames]
+        ins.append(([ctx.array(p) for p in pts], [len(p) for p in pts],
+                    [ctx.array(synth.image_frame(s, f)) for s, f in frames]))
+    got = []
+    for k, (d_pts, n, d_imgs) in enumerate(ins):
+        nxt = ins[k + 1] if k + 1 < len(ins) else None
+        pipe2.run(d_pts, n, d_imgs, lookahead=nxt)
+        if k > 0:
+            ctx.sync()
+            got.append((pipe2.d_records.download().copy(), pipe2.d_rec_counts.download().copy()))
+    pipe2.finish()
+    ctx.sync()
+    got.append((pipe2.d_records.download().copy(), pipe2.d_rec_counts.download().copy()))
+    assert len(got) == len(steps)
+    for k, (d_pts, n, d_imgs) in enumerate(ins):
+        for pair in range(2):
+            sl = slice(2 * pair, 2 * pair + 2)
+            pipe1.run(d_pts[sl], n[sl], d_imgs[sl])
+            pipe1.finish()
+            ctx.sync()
+            want, want_n = pipe1.d_records.download()[0], pipe1.d_rec_counts.download().reshape(-1)[:2]
+            assert np.array_equal(got[k][1].reshape(-1)[2 * pair:2 * pair + 2], want_n), (k, pair)
+            assert want_n.min() > 0
+            assert np.array_equal(got[k][0][pair], want), (k, pair)
+            assert np.any(want[0][:, 9:12] != 0)        # the T branch's offsets are in the first frame's records
+    pipe1.close()
+    pipe2.close()
