@@ -117,3 +117,20 @@ def test_template_bf16_kernel_matches_the_same_bars():
                         '-x', '-k', 'not template_bf16'], env=env, cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_bev_pyramid_bf16_full_size():
+    """One 700 x 800 BEV frame through the bf16 path at its real size -- 2 950 tiles of the folded first layers and of the
+    streaming kernel, four items per workgroup, the grouped queues with all eight groups, partial tiles at the bottom
+    (704 = 117 x 6 + 2 rows) -- against the same bars."""
+    rng = np.random.default_rng(7008)
+    x = rng.uniform(0, 1, size=(1, 700, 800, 6)).astype(np.float32)
+    x[x < 0.97] = 0
+    _run(BevVggPyr, x, synth.pyramid_params(6, seed=42), 4)
+
+
+def test_img_pyramid_bf16_full_size():
+    """... and one 360 x 1200 image frame (the padded-image form of the folded first layers: K = 36, two taps per lane half)."""
+    rng = np.random.default_rng(36012)
+    x = rng.normal(0, 60, size=(1, 360, 1200, 3)).astype(np.float32)
+    _run(ImgVggPyr, x, synth.pyramid_params(3, seed=142), 0)
