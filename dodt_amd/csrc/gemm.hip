@@ -560,9 +560,13 @@ int launch_fc_dma(hipStream_t s, const GemmArgs& a_in, int Npad) {
 constexpr int kBfBM = 64, kBfBN = 128, kBfStages = 3;
 __host__ __device__ constexpr int bf_swz(int r, int S) { return (r / (16 / S)) & (S - 1); }
 
-template <bool YBF16, int BK>
+template <bool YBF16, int BK, int R = kBfStages>
 __global__ void __launch_bounds__(256, 2)
 fc_bf16_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    // R: ring of stage images (three; six with DODT_FC_BF16_DMA_RING=6 and BK = 32: at M = 1024 a layer is 256 workgroups,
+    // one per CU, and two 12 KB stages on their way per CU are less than the memory system's latency x bandwidth -- see
+    // launch_fc_bf16_dma for what that bought)
+    static_assert((R - 2) * ((kBfBM + kBfBN) * BK * 2 / 1024 / 4) <= 63, "vmcnt is six bits");
     using dodt::i32x4_t;
     using dodt::kOob;
     using dodt::make_rsrc;
@@ -622,11 +626,11 @@ fc_bf16_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     const int w_base = kXBytes + (wn * 64 + li) * (BK * 2);
     auto stage = [&](auto bufc, int st) {
         constexpr int BUF = decltype(bufc)::value;
-        // stage st has landed once all but the copies of stage st + 1 are done
-        if (st + 1 < nstages) __builtin_amdgcn_s_waitcnt(0x0f70 | kPerStage);   // vmcnt(kPerStage)
+        // stage st has landed once all but the copies of stages st + 1 .. st + R - 2 are done (fewer near the end: drain)
+        if (st + R - 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * kPerStage) : "memory");
         else __builtin_amdgcn_s_waitcnt(0x0f70);                                  // vmcnt(0)
-        __builtin_amdgcn_s_barrier();     // ... for every wave; buffer (BUF + 2) % 3 is free
-        const bool more = st + 2 < nstages;
+        __builtin_amdgcn_s_barrier();     // ... for every wave; buffer (BUF + R - 1) % R is free
+        const bool more = st + R - 1 < nstages;
         const char* sS = reinterpret_cast<const char*>(smem) + BUF * kStage;
         f32x4 xf[NQ], wf[NQ][2];
         auto read_q = [&](int q) {
@@ -649,7 +653,7 @@ fc_bf16_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
                 // the copies of stage st + 2 spread over the k-steps
                 constexpr int kPerQ = (kPerStage + NQ - 1) / NQ;
 #pragma unroll
-                for (int n = q * kPerQ; n < (q + 1) * kPerQ && n < kPerStage; ++n) issue_one(st + 2, (BUF + 2) % kBfStages, n);
+                for (int n = q * kPerQ; n < (q + 1) * kPerQ && n < kPerStage; ++n) issue_one(st + R - 1, (BUF + R - 1) % R, n);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -658,12 +662,19 @@ fc_bf16_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
 #pragma unroll
         for (int n = 0; n < kPerStage; ++n) issue_one(st, buf, n);
     };
-    issue(0, 0);
-    if (nstages > 1) issue(1, 1);
-    for (int st = 0; st < nstages; st += 3) {
+#pragma unroll
+    for (int b = 0; b < R - 1; ++b)
+        if (b < nstages) issue(b, b);
+    for (int st = 0; st < nstages; st += R) {
         stage(std::integral_constant<int, 0>{}, st);
         if (st + 1 < nstages) stage(std::integral_constant<int, 1>{}, st + 1);
         if (st + 2 < nstages) stage(std::integral_constant<int, 2>{}, st + 2);
+        if constexpr (R > 3) {
+            if (st + 3 < nstages) stage(std::integral_constant<int, 3 % R>{}, st + 3);
+            if (st + 4 < nstages) stage(std::integral_constant<int, 4 % R>{}, st + 4);
+            if (st + 5 < nstages) stage(std::integral_constant<int, 5 % R>{}, st + 5);
+        }
+        static_assert(R == 3 || R == 6, "the stage loop is unrolled for rings of three or six");
     }
     // epilogue: bias + activation; lane = feature, registers = samples; bf16 output: round to nearest even
     const int n0 = nt0 * kBfBN;
@@ -689,7 +700,12 @@ fc_bf16_dma_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
 
 int launch_fc_bf16_dma(hipStream_t s, const GemmArgs& a, int Npad, bool y_bf16, int bk) {
     const int tiles_m = dodt::ceil_div(a.M, kBfBM), tiles_n = Npad / kBfBN;
-    const size_t lds = (size_t)kBfStages * (kBfBM + kBfBN) * bk * 2;
+    // (DODT_FC_BF16_DMA_RING=6: six stage images instead of three -- measured at the end of round 4: 16.7 -> 14.8 us at
+    //  M = 1024 (one workgroup per CU), 27.8 -> 29.5 / 52.6 -> 59.2 us at M = 2048 / 4096 (two per CU), and 980-992 against
+    //  995-1 012 pairs/s in the bf16 pipeline: opt-in)
+    static const int ring = getenv("DODT_FC_BF16_DMA_RING") && atoi(getenv("DODT_FC_BF16_DMA_RING")) == 6 ? 6 : 3;
+    const int stages = bk == 64 ? kBfStages : ring;
+    const size_t lds = (size_t)stages * (kBfBM + kBfBN) * bk * 2;
     auto go = [&](auto kernel) -> hipError_t {
         static std::mutex mu;
         static std::set<const void*> prepared;
@@ -707,6 +723,7 @@ int launch_fc_bf16_dma(hipStream_t s, const GemmArgs& a, int Npad, bool y_bf16, 
     };
     hipError_t e;
     if (bk == 64) e = y_bf16 ? go(&fc_bf16_dma_kernel<true, 64>) : go(&fc_bf16_dma_kernel<false, 64>);
+    else if (stages == 6) e = y_bf16 ? go(&fc_bf16_dma_kernel<true, 32, 6>) : go(&fc_bf16_dma_kernel<false, 32, 6>);
     else e = y_bf16 ? go(&fc_bf16_dma_kernel<true, 32>) : go(&fc_bf16_dma_kernel<false, 32>);
     DODT_HIP_CHECK(e);
     DODT_LAUNCH_CHECK();

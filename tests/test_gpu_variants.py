@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     # the bf16-row GEMM with 64-k stages (default 32)
     ({'DODT_FC_BF16_DMA_BK': '64'}, ['tests/test_gpu_heads.py', '-k', 'bf16_rows']),
+    # ... with a ring of six stage images (default three)
+    ({'DODT_FC_BF16_DMA_RING': '6'}, ['tests/test_gpu_heads.py', '-k', 'bf16_rows']),
     # bf16 heads on float32 activations, rounded on every load (round 3's form), through the whole pair
     ({'DODT_FC_BF16_ROWS': '0'}, ['tests/test_gpu_heads.py', '-k', 'stagewise and bf16']),
     # correlation: 512-lane workgroups with the channels split over half-waves; round 3's two-pass kernel
